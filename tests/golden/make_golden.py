@@ -1,0 +1,175 @@
+"""Golden-vector generator: imports the REFERENCE model code from /root/reference through a small
+compatibility shim and records its outputs on seeded inputs.
+
+Runs only in the build container (needs /root/reference; nothing here travels as source to the GPU
+box except this script and the .npz files it writes).  Usage:
+
+    python tests/golden/make_golden.py [--long]      # --long also records 1024-token decodes
+
+The shim adapts the installed transformers 5.15 to the 4.18 API the reference was
+written against; it does not change any arithmetic:
+  1. modeling_t5.checkpoint        -> torch.utils.checkpoint.checkpoint (import fails otherwise)
+  2. T5PreTrainedModel.get_head_mask(head_mask, n) -> [None]*n           (removed in 5.x)
+  3. get_extended_attention_mask(mask, shape, device) with 4.18 semantics: causal for decoders,
+     additive (1-m)*-10000.0
+  4. invert_attention_mask with 4.18's (1-m)*-1e9
+  5. config.tie_word_embeddings forced back to False after T5Config.from_dict (5.15 overrides it)
+Weights are set explicitly from the golden recipe (never the default init: under 5.15 it breaks
+the additive -10000 causal mask); eager attention; eval mode.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "mr-mt3_amd"))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel, synth_labels  # noqa: E402
+
+
+def install_shim():
+    import transformers.models.t5.modeling_t5 as mt5
+    import torch.utils.checkpoint
+    from transformers import T5PreTrainedModel
+
+    mt5.checkpoint = torch.utils.checkpoint.checkpoint
+
+    def get_head_mask(self, head_mask, num_hidden_layers, is_attention_chunked=False):
+        return [None] * num_hidden_layers
+
+    def get_extended_attention_mask(self, attention_mask, input_shape, device=None, dtype=None):
+        # transformers 4.18 semantics
+        if attention_mask.dim() == 3:
+            ext = attention_mask[:, None, :, :]
+        elif attention_mask.dim() == 2:
+            if self.config.is_decoder:
+                bsz, seq = input_shape
+                ids = torch.arange(seq, device=attention_mask.device)
+                causal = (ids[None, None, :].repeat(bsz, seq, 1) <= ids[None, :, None]).to(attention_mask.dtype)
+                if causal.shape[1] < attention_mask.shape[1]:
+                    pre = attention_mask.shape[1] - causal.shape[1]
+                    causal = torch.cat([torch.ones((bsz, seq, pre), dtype=causal.dtype), causal], axis=-1)
+                ext = causal[:, None, :, :] * attention_mask[:, None, None, :]
+            else:
+                ext = attention_mask[:, None, None, :]
+        else:
+            raise ValueError("bad mask")
+        ext = ext.to(dtype=torch.float32)
+        return (1.0 - ext) * -10000.0
+
+    def invert_attention_mask(self, encoder_attention_mask):
+        if encoder_attention_mask.dim() == 3:
+            ext = encoder_attention_mask[:, None, :, :]
+        else:
+            ext = encoder_attention_mask[:, None, None, :]
+        ext = ext.to(dtype=torch.float32)
+        return (1.0 - ext) * -1e9
+
+    T5PreTrainedModel.get_head_mask = get_head_mask
+    T5PreTrainedModel.get_extended_attention_mask = get_extended_attention_mask
+    T5PreTrainedModel.invert_attention_mask = invert_attention_mask
+
+
+def build_reference(variant: str, segmem_length: int = 64):
+    sys.path.insert(0, "/root/reference")
+    from transformers import T5Config
+    cfg = dict(T5_SMALL)
+    cfg["use_cache"] = False
+    tc = T5Config.from_dict(cfg)
+    tc._attn_implementation = "eager"
+    # 5th patch: transformers 5.15's T5Config forces tie_word_embeddings=True (and would tie
+    # lm_head to decoder_embed_tokens and rescale by d_model^-0.5); under the pinned 4.18 the
+    # reference's config (`tie_word_embeddings: false`, config/model/MT3Net.yaml:22) is honoured.
+    tc.tie_word_embeddings = False
+    if variant == "t5":
+        from models.t5 import T5ForConditionalGeneration as M
+        m = M(tc)
+        seg_layers = 0
+    else:
+        mod = {"segmem_v1": ("models.t5_segmem", "T5SegMem"),
+               "segmem_v2": ("models.t5_segmem_v2", "T5SegMemV2"),
+               "segmem_v2_with_prev": ("models.t5_segmem_v2_with_prev", "T5SegMemV2WithPrev")}[variant]
+        import importlib
+        M = getattr(importlib.import_module(mod[0]), mod[1])
+        m = M(tc, segmem_num_layers=1, segmem_length=segmem_length)
+        seg_layers = 1
+    w = golden_weights(T5_SMALL, seg_layers)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    # only aliases and inv_freq buffers may be missing
+    bad = [k for k in missing if not (k.endswith("embed_tokens.weight") or k.endswith("inv_freq"))]
+    assert not bad and not unexpected, (bad, unexpected)
+    assert m.lm_head.weight.data_ptr() != m.decoder_embed_tokens.weight.data_ptr()
+    assert not m.config.tie_word_embeddings
+    for k, v in sd.items():   # every recipe tensor really is what the model holds
+        assert torch.equal(m.state_dict()[k], v), k
+    m.eval()
+    return m
+
+
+def sample_idx(shape, n, seed):
+    rs = np.random.RandomState(seed)
+    return rs.randint(0, int(np.prod(shape)), size=n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--long", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    install_shim()
+    out = {}
+    B = 2
+    mel = torch.from_numpy(synth_mel(B))
+    lab_full = torch.from_numpy(synth_labels(B, full=True))
+    lab_pad = torch.from_numpy(synth_labels(B, full=False, seed=777))
+    prev = torch.from_numpy(synth_labels(B, full=False, seed=999))
+    import torch.nn.functional as F
+
+    for variant in ("t5", "segmem_v1", "segmem_v2", "segmem_v2_with_prev"):
+        t0 = time.time()
+        m = build_reference(variant)
+        with torch.no_grad():
+            for tag, lab in (("full", lab_full), ("pad", lab_pad)):
+                kw = {}
+                if variant == "segmem_v2_with_prev":
+                    kw["targets_prev"] = prev.clone()     # mutated in place by the reference
+                logits = m(inputs=mel, labels=lab, **kw)
+                loss = F.cross_entropy(logits.view(-1, logits.shape[-1]).double(), lab.view(-1), ignore_index=-100)
+                idx = sample_idx(logits.shape, 4096, 1234)
+                out[f"{variant}.{tag}.loss"] = np.float64(loss.item())
+                out[f"{variant}.{tag}.logit_idx"] = idx.astype(np.int64)
+                out[f"{variant}.{tag}.logit_val"] = logits.reshape(-1)[idx].numpy().astype(np.float32)
+                out[f"{variant}.{tag}.argmax"] = logits.argmax(-1).numpy().astype(np.int16)
+                out[f"{variant}.{tag}.logit_absmax"] = np.float32(logits.abs().max().item())
+            if variant == "t5":
+                # per-sublayer activations of a 1-layer slice (encoder block 0) for kernel-level tests
+                x = m.proj(mel)
+                out["t5.slice.proj"] = x[0, :8].numpy()
+                enc = m.encoder(inputs_embeds=x, return_dict=True)[0]
+                out["t5.slice.enc_out"] = enc[:, ::37, ::5].numpy()
+            # greedy decode (reference algorithm, no KV cache)
+            for ml in ((32, 256, 1024) if args.long else (32, 256)):
+                if variant in ("segmem_v1",):
+                    continue
+                ids = m.generate(inputs=mel, max_length=ml)
+                out[f"{variant}.gen{ml}"] = ids.numpy().astype(np.int16)
+                print(variant, "gen", ml, ids.shape, "t=%.1fs" % (time.time() - t0), flush=True)
+        print(variant, "done in %.1fs" % (time.time() - t0), flush=True)
+
+    np.savez_compressed(os.path.join(HERE, "model_golden.npz"), **out)
+    print("wrote", os.path.join(HERE, "model_golden.npz"), {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""Pins the CPU oracle (oracle/t5_ref.py) against vectors recorded from the reference itself
+(tests/golden/make_golden.py, run in the build container through the HF-compat shim)."""
+import numpy as np
+import pytest
+import torch
+
+from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel, synth_labels
+from oracle import t5_ref
+
+VARIANTS = ["t5", "segmem_v1", "segmem_v2", "segmem_v2_with_prev"]
+
+
+def _sd(variant):
+    w = golden_weights(T5_SMALL, 0 if variant == "t5" else 1)
+    return {k: torch.from_numpy(v) for k, v in w.items()}
+
+
+def _inputs():
+    B = 2
+    return (torch.from_numpy(synth_mel(B)), torch.from_numpy(synth_labels(B, full=True)),
+            torch.from_numpy(synth_labels(B, full=False, seed=777)),
+            torch.from_numpy(synth_labels(B, full=False, seed=999)))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("tag", ["full", "pad"])
+def test_logits_and_loss_match_reference(golden, variant, tag):
+    torch.set_num_threads(8)
+    mel, lab_full, lab_pad, prev = _inputs()
+    lab = lab_full if tag == "full" else lab_pad
+    with torch.no_grad():
+        logits = t5_ref.forward_logits(_sd(variant), T5_SMALL, mel, lab, variant=variant,
+                                       targets_prev=prev.clone())
+    idx = golden[f"{variant}.{tag}.logit_idx"]
+    got = logits.reshape(-1)[idx].numpy()
+    np.testing.assert_allclose(got, golden[f"{variant}.{tag}.logit_val"], atol=2e-5, rtol=0)
+    loss = t5_ref.ce_loss(logits.double(), lab).item()
+    assert abs(loss - float(golden[f"{variant}.{tag}.loss"])) < 1e-5
+    agree = (logits.argmax(-1).numpy() == golden[f"{variant}.{tag}.argmax"]).mean()
+    assert agree > 0.999
+
+
+def test_greedy_t5_matches_reference(golden):
+    mel = torch.from_numpy(synth_mel(2))
+    with torch.no_grad():
+        ids = t5_ref.generate_t5(_sd("t5"), T5_SMALL, mel, max_length=32)
+    np.testing.assert_array_equal(ids.numpy(), golden["t5.gen32"])
+
+
+@pytest.mark.parametrize("variant", ["segmem_v2", "segmem_v2_with_prev"])
+def test_greedy_segmem_matches_reference(golden, variant):
+    mel = torch.from_numpy(synth_mel(2))
+    with torch.no_grad():
+        ids = t5_ref.generate_segmem_v2(_sd(variant), T5_SMALL, mel, max_length=32,
+                                        with_prev=variant.endswith("prev"))
+    np.testing.assert_array_equal(ids.numpy(), golden[f"{variant}.gen32"])
+
+
+def test_cosine_schedule_known_answers():
+    # utils.py:53-61 — warmup is linear, min_lr floors the multiplier
+    f = lambda s: t5_ref.cosine_lambda(s, 100, 1000, min_lr=1e-4)
+    assert f(0) == 0.0 and f(50) == 0.5 and f(100) == 1.0
+    assert abs(f(550) - 0.5) < 1e-12
+    assert f(1000) == 1e-4 and f(999) >= 1e-4
