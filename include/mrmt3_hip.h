@@ -1,0 +1,208 @@
+/* mrmt3_hip.h — C ABI of libmrmt3_hip.so: the MI355X (gfx950) kernels of the MR-MT3 hot path.
+ *
+ * The reference (gudgud96/MR-MT3) is pure Python: this path has NO FFI in the reference.  The
+ * boundary it replaces is the chain of stock PyTorch / HuggingFace / torchaudio ops called from
+ *   contrib/spectrograms.py:105-145          compute_spectrogram            -> mrmt3_logmel_fwd
+ *   models/t5.py:99-180, 478-702             T5Stack wiring over HF T5Block  -> gemm / norm / attn /
+ *                                                                              geglu / embed entry points
+ *   tasks/mt3_net.py:32-35                   CrossEntropyLoss(ignore=-100)   -> mrmt3_ce_fwd_bwd
+ *   tasks/mt3_net.py:54-68                   AdamW + LambdaLR                -> mrmt3_adamw_step
+ *   models/t5.py:251-302, t5_segmem_v2_with_prev.py:226-296  greedy generate -> mrmt3_decoder_*
+ * Each entry point cites the reference lines it stands for.  INTEGRATION.md shows the ctypes
+ * binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - Plain C: pointers are raw DEVICE pointers into caller-owned allocations (torch tensors); sizes
+ *    and strides are explicit, in ELEMENTS unless a name ends in _bytes.  No torch types.
+ *  - dtype codes: MRMT3_F32 (float) or MRMT3_BF16 (raw bfloat16 bits, uint16_t).
+ *  - Every call is asynchronous on the hipStream_t passed as `void* stream`, re-entrant across
+ *    streams, never synchronises the device and never allocates (graph-capture safe).  The only
+ *    library-owned objects are the opaque mrmt3_decoder handles.
+ *  - Return value: 0 = MRMT3_OK, otherwise an error code; mrmt3_last_error() returns a
+ *    thread-local message.  Nothing aborts or throws across this ABI.
+ */
+#ifndef MRMT3_HIP_H
+#define MRMT3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRMT3_OK 0
+#define MRMT3_ERR_INVALID_ARG 1
+#define MRMT3_ERR_HIP 2
+#define MRMT3_ERR_UNSUPPORTED 3
+
+#define MRMT3_F32 0
+#define MRMT3_BF16 1
+
+/* ABI version (major*10000 + minor*100 + patch) and last error text of the calling thread. */
+int mrmt3_version(void);
+const char* mrmt3_last_error(void);
+
+/* ---- K1: log-mel frontend ---------------------------------------------------------------------
+ * contrib/spectrograms.py:92-103,128-145 (pad_end, MelSpectrogram(n_fft 2048, hop, power 1,
+ * center False), safe_log) + dataset/dataset_2_random.py:288-289 (clip/scale when normalize!=0)
+ * + inference.py:125-126 (frames >= valid_frames[b] are zeroed; valid_frames may be NULL).
+ * audio [batch][n_samples] f32 -> out [batch][ceil(n_samples/hop)][n_mels] f32 (or bf16).
+ * window [2048] f32; twiddle [1024][2] f32 = exp(-2*pi*i*k/2048); the filterbank is passed in
+ * compressed rows: filter m = sum_{q<fb_cnt[m]} fb_w[m*max_taps+q] * |X[fb_start[m]+q]|. */
+int mrmt3_logmel_fwd(const float* audio, int batch, int n_samples, int hop, const float* window,
+                     const float* twiddle, const int* fb_start, const int* fb_cnt, const float* fb_w,
+                     int n_mels, int max_taps, const int* valid_frames, int normalize, int out_bf16,
+                     void* out, void* stream);
+
+/* ---- K2/K4/K6/K7/K9: bias-free Linear layers (nn.Linear(bias=False) inside HF T5Block,
+ * models/t5.py:51,72,487-490) ----------------------------------------------------------------------
+ * NT:  C[M,N] (+)= A[M,K] . B[N,K]^T      forward y = x W^T, and dgrad with a pre-transposed W.
+ * in_dtype applies to A and B; out_dtype to C; accumulate!=0 adds to the existing C (f32 only).
+ * Requirements: K*sizeof(in) % 128 == 0; lda/ldb/ldc are row strides in elements. */
+int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
+                  int K, int in_dtype, int out_dtype, int accumulate, void* stream);
+/* TN (weight gradient):  C[N1,N2] (+)= A[M,N1]^T . B[M,N2], bf16 inputs, f32 output, reduction over
+ * the M rows split across workgroups; `workspace` must hold mrmt3_gemm_tn_workspace_bytes(...). */
+size_t mrmt3_gemm_tn_workspace_bytes(int M, int N1, int N2);
+int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1,
+                  int N2, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K3: T5LayerNorm (RMS norm) fused with the residual add and dropout that precede it --------
+ * HF T5LayerNorm + `hidden + dropout(sublayer_out)` (T5LayerSelfAttention/CrossAttention/FF), and
+ * models/t5.py:598-601,676-678.
+ *   x1 = x0 + dropmask(y)            (y may be NULL: x1 = x0;  x1 may alias x0)
+ *   xn = x1 * rsqrt(mean(x1^2)+eps) * w      -> xn (act_dtype), rstd[rows]
+ *   out_drop!=0 additionally applies dropout to xn (final_layer_norm + dropout, t5.py:676-678).
+ * Dropout masks are regenerated from (seed, stream_id, element index); p==0 disables them. */
+int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const float* w, float eps,
+                          float* x1, void* xn, int xn_dtype, float* rstd, int rows, int cols,
+                          float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                          int out_drop, void* stream);
+/* backward of the above:
+ *   g    = dxn (f32) [* out-dropout mask]
+ *   dx1  = dres (nullable) + rmsnorm_bwd(g; x1, rstd, w)          -> dx1 (f32; may alias dres)
+ *   dy   = dropmask_y(dx1) as bf16 (nullable)                      -> dy
+ *   dw  += sum_rows g * x1 * rstd                                  (f32 atomics into dw[cols]) */
+int mrmt3_add_rmsnorm_bwd(const float* dxn, const float* dres, const float* x1, const float* rstd,
+                          const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
+                          float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                          int out_drop, void* stream);
+
+/* ---- K5: attention core (HF T5Attention without relative bias: softmax(q k^T [+causal]) v, scale
+ * 1.0, fp32 softmax; models/t5.py:487-490,636-648) -------------------------------------------------
+ * q [B][Lq][*] , k/v [B][Lk][*] with head h at columns [h*64, h*64+64) of the row (row strides
+ * ldq/ldk/ldv/ldo in elements; batch strides = L*ld).  head_dim is fixed at 64 (d_kv).
+ * o [B][Lq][H*64] (ldo), lse [B][H][Lq] f32.  causal!=0 masks key > query.  Attention-probability
+ * dropout (p_drop) uses a counter hash of (seed, b, h, q, k).  dtype = MRMT3_BF16 (MFMA flash
+ * kernel) or MRMT3_F32 (exact-f32 reference-grade kernel used for parity/decoding). */
+int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
+                   int ldo, float* lse, int B, int H, int Lq, int Lk, int causal, int dtype,
+                   float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+/* backward (bf16 only): delta [B][H][Lq] f32 scratch is written by the call.
+ * dq/dk/dv share the layout (and strides) of q/k/v. */
+int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                   const void* o, int ldo, const void* d_o, int lddo, const float* lse, float* delta,
+                   void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Lq,
+                   int Lk, int causal, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* ---- K7: gated-GELU (HF T5DenseGatedGeluDense: gelu_new(h0) * h1, then dropout) ----------------
+ * h [rows][2*dff] = [wi_0 x | wi_1 x] -> g [rows][dff] */
+int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop,
+                    uint64_t seed, uint32_t stream_id, void* stream);
+int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
+                    uint64_t seed, uint32_t stream_id, void* stream);
+
+/* ---- K8: embedding gather + sinusoid add (+dropout) and its scatter-add backward ---------------
+ * models/t5.py:539-540,596-601 and `_shift_right` (t5.py:148-150).
+ * ids [rows] int64.  shift!=0 applies HF _shift_right inside the gather: position t of a
+ * sequence of length seq_len uses ids[t-1] (start_id at t==0) and maps -100 -> pad_id.
+ * x [rows][d] f32 = table[id] + pos[(row % seq_len) + pos_offset], then dropout. */
+int mrmt3_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* x, int rows,
+                    int seq_len, int d, int vocab, int shift, int start_id, int pad_id,
+                    int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+/* dtable[id] += dropmask(dx[row])   (f32 atomics) */
+int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtable, int rows, int seq_len, int d,
+                    int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed,
+                    uint32_t stream_id, void* stream);
+/* x[rows][d] f32 = src[rows][d] (src_dtype) + pos[(row % seq_len)+pos_offset], then dropout
+ * (the encoder side of models/t5.py:596-601, input = proj(mel)); backward is dropmask only. */
+int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos, float* x, int rows, int seq_len,
+                     int d, int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id,
+                     void* stream);
+/* out_bf16 = dropmask(dx)  (gradient w.r.t. the GEMM output feeding addpos / any dropout site) */
+int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed,
+                        uint32_t stream_id, void* stream);
+
+/* ---- K9: cross-entropy over lm_head logits (tasks/mt3_net.py:32-35; weighted variant :96-108) ---
+ * logits [rows][V] f32, targets [rows] int64 (ignore_index -100).  Per row (w_i, n_i) = (1,1) for a
+ * normal target, (3,2) for an instrument token in [inst_lo,inst_hi] when weighted!=0 (the
+ * reference's `sum_nonpad + 2*sum_inst` over `n_inst + n_nonpad`), (0,0) for ignored rows.
+ * mrmt3_ce_count:   denom_dev[0] += sum_i n_i                      (zero it first)
+ * mrmt3_ce_fwd_bwd: loss_dev[0]  += sum_i w_i * nll_i / denom      (zero it first)
+ *                   dlogits (nullable, dl_dtype) = grad_scale * w_i * (softmax_i - onehot_i) / denom
+ * Both scalars stay on the device: no host synchronisation. */
+int mrmt3_ce_count(const int64_t* targets, int rows, int weighted, int inst_lo, int inst_hi,
+                   float* denom_dev, void* stream);
+int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* denom_dev,
+                     float* loss_dev, void* dlogits, int dl_dtype, int rows, int V, int weighted,
+                     int inst_lo, int inst_hi, float grad_scale, void* stream);
+
+/* ---- K11: AdamW over the flat parameter buffer (torch.optim.AdamW defaults; tasks/mt3_net.py:55)
+ * p,g,m,v: flat f32 [n].  lr is read from lr_dev[0] (device), step count from step_dev[0] (int32,
+ * incremented by the call).  grad_scale multiplies g (e.g. 1/world_size).  shadow_bf16 (nullable)
+ * receives the updated parameters in bf16. */
+int mrmt3_adamw_step(float* p, const float* g, float* m, float* v, size_t n, const float* lr_dev,
+                     int32_t* step_dev, float beta1, float beta2, float eps, float weight_decay,
+                     float grad_scale, void* shadow_bf16, void* stream);
+/* out[c][r] = in[r][c] (2-D transpose, with optional f32->bf16 cast) for the pre-transposed dgrad
+ * weights. */
+int mrmt3_transpose(const void* in, int in_dtype, void* out, int out_dtype, int rows, int cols,
+                    void* stream);
+int mrmt3_cast(const void* in, int in_dtype, void* out, int out_dtype, size_t n, void* stream);
+
+/* ---- K12: greedy decode with a KV cache, one hipGraph replay per token -------------------------
+ * models/t5.py:251-302 (batched, MT3Net) and models/t5_segmem_v2_with_prev.py:273-291 (B=1 per
+ * segment).  The decoder handle owns: the captured graph, the self-attention KV cache
+ * [layers][2][B][max_len][H*64], scratch activations and the device-side step/finished state.
+ * Weights are referenced, not copied: `weights` is an array of mrmt3_decoder_weights (device
+ * pointers into the caller's flat parameter buffer, dtype = act dtype of the handle). */
+typedef struct mrmt3_decoder mrmt3_decoder;
+typedef struct {
+  const void* embed;        /* [vocab][d] f32 decoder_embed_tokens */
+  const float* pos;         /* [>=max_len][d] f32 sinusoid table */
+  const void* lm_head;      /* [vocab][d] */
+  const float* final_ln;    /* [d] */
+  /* per layer l (arrays of n_layers pointers on the HOST): */
+  const float* const* ln_self;   /* [d] */
+  const void* const* w_qkv;      /* [3*inner][d]  (q|k|v rows) */
+  const void* const* w_o_self;   /* [d][inner] */
+  const float* const* ln_cross;  /* [d] */
+  const void* const* w_q_cross;  /* [inner][d] */
+  const void* const* w_o_cross;  /* [d][inner] */
+  const float* const* ln_ff;     /* [d] */
+  const void* const* w_wi;       /* [2*dff][d]   (wi_0|wi_1 rows) */
+  const void* const* w_wo;       /* [d][dff] */
+} mrmt3_decoder_weights;
+
+int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_model, int n_heads, int d_ff,
+                         int vocab, int max_batch, int max_len, int max_enc_len, int w_dtype,
+                         float eps);
+void mrmt3_decoder_destroy(mrmt3_decoder* dec);
+/* Start a batch: cross_k/cross_v [layers][B][Lenc][inner] (act dtype = w_dtype) are caller-owned
+ * (computed with mrmt3_gemm_nt from the encoder output); resets positions, finished flags and
+ * writes start_id as token 0.  tokens_out [B][max_len+1] int64 is caller-owned. */
+int mrmt3_decoder_begin(mrmt3_decoder* dec, const mrmt3_decoder_weights* w, const void* cross_k,
+                        const void* cross_v, int batch, int enc_len, int64_t* tokens_out,
+                        int start_id, int eos_id, int pad_id, int stop_at_eos_mode, void* stream);
+/* Run n_steps decode steps (graph replays; captured on first use).  No host synchronisation. */
+int mrmt3_decoder_run(mrmt3_decoder* dec, int n_steps, void* stream);
+/* state_out[0] = steps taken so far, [1] = 1 if every row has emitted EOS, [2] = step index at
+ * which the last row finished (or -1).  Copies 3 int32 asynchronously to caller-owned PINNED host
+ * memory; the caller synchronises the stream before reading. */
+int mrmt3_decoder_poll(mrmt3_decoder* dec, int32_t* state_out_pinned, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRMT3_HIP_H */

@@ -1,0 +1,606 @@
+// K5 — attention core of the T5 block for gfx950 (head_dim 64, any head count — T5-small has 6).
+//
+// Stands for HF T5Attention as the reference instantiates it (models/t5.py:487-490: no relative
+// position bias; scores = q.k^T UNSCALED, + causal mask for the decoder's self-attention
+// (4.18 get_extended_attention_mask, models/t5.py:567-568), softmax in fp32, dropout on the
+// probabilities, then p.v), and for its autograd backward.
+//
+// bf16 kernels are flash-style (never materialise [B,H,Lq,Lk]); fp32 softmax statistics.
+//   forward : workgroup = 128 query rows of one (batch, head); 4 waves x 32 rows.  K/V tiles of 64
+//             keys are staged global->regs->LDS (double buffered, 160-B row stride = conflict-free
+//             for both ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads).
+//             The scores are computed TRANSPOSED (S^T = K.Q^T, query on the MFMA lane) so that the
+//             softmax row statistics are per-lane scalars and the exponentiated tile is already the
+//             B operand of O^T = V^T.P^T (accumulator-as-operand, no LDS round trip for P).
+//   backward: (1) delta = rowsum(dO*O); (2) dK/dV: workgroup = 128 keys, key on the lane, loops
+//             over 32-query blocks; (3) dQ: workgroup = 128 queries, query on the lane, loops over
+//             64-key tiles.  P is recomputed from the saved log-sum-exp.  No atomics: every output
+//             element has exactly one writer, results are bitwise reproducible.
+// The f32 kernel is a plain exact-f32 implementation used for the fp32 parity / greedy-decode path.
+#include "common.h"
+
+#define HD 64          // head dim (d_kv)
+#define KV_STRIDE 160  // bytes per LDS row of a [rows][64] bf16 tile
+
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
+  return bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (short)f2bf(lo[0]); r[1] = (short)f2bf(lo[1]); r[2] = (short)f2bf(lo[2]); r[3] = (short)f2bf(lo[3]);
+  r[4] = (short)f2bf(hi[0]); r[5] = (short)f2bf(hi[1]); r[6] = (short)f2bf(hi[2]); r[7] = (short)f2bf(hi[3]);
+  return r;
+}
+
+// attention-probability dropout: 16 random bits per (b,h,q,k) element from a counter hash
+struct AttnDrop {
+  unsigned seed_lo, seed_hi;
+  unsigned thresh16;  // p * 65536; 0 = off
+  float scale;
+};
+__host__ inline AttnDrop make_attn_drop(float p, unsigned long long seed, unsigned stream) {
+  AttnDrop d;
+  d.seed_lo = (unsigned)seed ^ (stream * 0x9E3779B9u);
+  d.seed_hi = (unsigned)(seed >> 32) + stream;
+  if (p <= 0.f) { d.thresh16 = 0; d.scale = 1.f; }
+  else { d.thresh16 = (unsigned)(p * 65536.0f + 0.5f); d.scale = 1.f / (1.f - p); }
+  return d;
+}
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16;
+  return x;
+}
+// keep-scale of element `idx` (flat (b,h,q,k) index)
+__device__ __forceinline__ float attn_keep(const AttnDrop& d, unsigned long long idx) {
+  const unsigned long long pair = idx >> 1;
+  unsigned h = hash32(((unsigned)pair ^ d.seed_lo) + hash32((unsigned)(pair >> 32) ^ d.seed_hi));
+  const unsigned r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return r >= d.thresh16 ? d.scale : 0.f;
+}
+
+struct AttnParams {
+  const bf16_t *q, *k, *v, *o, *d_o;
+  bf16_t *out, *dq, *dk, *dv;
+  float* lse;
+  float* delta;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int B, H, Lq, Lk, causal;
+  AttnDrop drop;
+};
+
+// stage a [ROWS][64] bf16 tile (row-major, KV_STRIDE) : thread handles chunk ids tid, tid+256, ...
+template <int ROWS>
+__device__ __forceinline__ void tile_gload(const bf16_t* base, int ld, int row0, int nrows_valid, int tid, u32x4* regs) {
+#pragma unroll
+  for (int i = 0; i < (ROWS * 8 + 255) / 256; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, ch = c & 7;
+    if (ROWS * 8 >= 256 || c < ROWS * 8) {
+      if (row0 + row < nrows_valid) regs[i] = *(const u32x4*)(base + (size_t)(row0 + row) * ld + ch * 8);
+      else regs[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void tile_lstore(unsigned char* lds, int tid, const u32x4* regs) {
+#pragma unroll
+  for (int i = 0; i < (ROWS * 8 + 255) / 256; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, ch = c & 7;
+    if (ROWS * 8 >= 256 || c < ROWS * 8) *(u32x4*)(lds + row * KV_STRIDE + ch * 16) = regs[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * KV_STRIDE];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
+  const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
+  const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
+  const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
+
+  // Q fragments (B operand): lane holds Q[q = qrow(qt)][d = 32ks + 8g .. +7]
+  bf16x8 qf[2][2];
+  int qrow[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qrow[qt] = q0 + wave * 32 + qt * 16 + fr;
+    const int r = min(qrow[qt], P.Lq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *(const bf16x8*)(qb + (size_t)r * P.ldq + ks * 32 + fg * 8);
+  }
+  f32x4 oT[2][4];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    m_run[qt] = -INFINITY;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oT[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  int n_kv = ceil_div(P.Lk, 64);
+  if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
+  u32x4 kr[2], vr[2];
+  tile_gload<64>(kb, P.ldk, 0, P.Lk, tid, kr);
+  tile_gload<64>(vb, P.ldv, 0, P.Lk, tid, vr);
+  tile_lstore<64>(&lds[0][0][0], tid, kr);
+  tile_lstore<64>(&lds[0][1][0], tid, vr);
+  __syncthreads();
+  const unsigned long long drop_base = ((unsigned long long)(b * P.H + h)) * P.Lq;
+
+  for (int j = 0; j < n_kv; ++j) {
+    const int cur = j & 1, kv0 = j * 64;
+    if (j + 1 < n_kv) {
+      tile_gload<64>(kb, P.ldk, kv0 + 64, P.Lk, tid, kr);
+      tile_gload<64>(vb, P.ldv, kv0 + 64, P.Lk, tid, vr);
+    }
+    const unsigned char* lk = &lds[cur][0][0];
+    const unsigned char* lv = &lds[cur][1][0];
+
+    // S^T = K . Q^T : sT[qt][kt] holds S^T[key = kt*16 + 4g + r][q = fr]
+    f32x4 sT[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      bf16x8 ka0 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + (fg) * 16);
+      bf16x8 ka1 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mfma16(ka0, qf[qt][0], acc);
+        acc = mfma16(ka1, qf[qt][1], acc);
+        sT[qt][kt] = acc;
+      }
+    }
+    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + wave * 32);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      if (need_mask) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + kt * 16 + fg * 4 + r;
+            if (key >= P.Lk || (P.causal && key > qrow[qt])) sT[qt][kt][r] = -INFINITY;
+          }
+      }
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sT[qt][kt][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mloc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __expf(m_run[qt] - m_use);
+      m_run[qt] = m_new;
+      float lsum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(sT[qt][kt][r] - m_use);
+          lsum += p;
+          sT[qt][kt][r] = p;
+        }
+      l_run[qt] = l_run[qt] * alpha + lsum;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oT[qt][dt] *= alpha;
+      if (P.drop.thresh16) {
+        const unsigned long long rowbase = (drop_base + (unsigned long long)qrow[qt]) * P.Lk + kv0;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sT[qt][kt][r] *= attn_keep(P.drop, rowbase + kt * 16 + fg * 4 + r);
+      }
+    }
+    // O^T += V^T . P^T : k-slot (g, j) of a 32-key step <-> key = 32*ks + 16*(j>>2) + 4g + (j&3)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pb[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) pb[qt] = pack8(sT[qt][2 * ks], sT[qt][2 * ks + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const unsigned char* a = lv + (ks * 32 + fg * 4 + fq) * KV_STRIDE + (dt * 16 + fp * 4) * 2;
+        bf16x8 vt = cat8(lds_tr16(a), lds_tr16(a + 16 * KV_STRIDE));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) oT[qt][dt] = mfma16(vt, pb[qt], oT[qt][dt]);
+      }
+    }
+    if (j + 1 < n_kv) {
+      tile_lstore<64>(&lds[cur ^ 1][0][0], tid, kr);
+      tile_lstore<64>(&lds[cur ^ 1][1][0], tid, vr);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qrow[qt] >= P.Lq) continue;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* orow = P.out + ((size_t)b * P.Lq + qrow[qt]) * P.ldo + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 v = oT[qt][dt] * inv;
+      *(u32x2*)(orow + dt * 16 + fg * 4) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    }
+    if (fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: delta = rowsum(dO * O) per (b, h, q)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams P) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*Lq + q
+  if (row >= (size_t)P.B * P.Lq) return;
+  const int b = (int)(row / P.Lq), q = (int)(row % P.Lq);
+  for (int h = 0; h < P.H; ++h) {
+    float a = bf2f(P.d_o[row * P.lddo + h * HD + lane]) * bf2f(P.o[row * P.ldo + h * HD + lane]);
+    a = wave_sum(a);
+    if (lane == 0) P.delta[((size_t)b * P.H + h) * P.Lq + q] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dK, dV.  workgroup = 128 keys (wave = 32 keys, key on the lane), loop over 32-query blocks
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * KV_STRIDE];  // [buf][Q|dO]
+  __shared__ float lstat[2][2][32];                                                  // [buf][lse|delta]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
+  const int k0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
+  const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
+  const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
+  const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
+  const float* lse = P.lse + ((size_t)b * P.H + h) * P.Lq;
+  const float* dlt = P.delta + ((size_t)b * P.H + h) * P.Lq;
+
+  bf16x8 kf[2][2], vf[2][2];
+  int key[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    key[nt] = k0 + wave * 32 + nt * 16 + fr;
+    const int r = min(key[nt], P.Lk - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[nt][ks] = *(const bf16x8*)(kb + (size_t)r * P.ldk + ks * 32 + fg * 8);
+      vf[nt][ks] = *(const bf16x8*)(vb + (size_t)r * P.ldv + ks * 32 + fg * 8);
+    }
+  }
+  f32x4 dkT[2][4], dvT[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dkT[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int qstart = P.causal ? (k0 / 32) * 32 : 0;
+  const int nblk = qstart < P.Lq ? ceil_div(P.Lq - qstart, 32) : 0;
+  u32x4 qr[1], dor[1];
+  float st_l = 0.f, st_d = 0.f;
+  auto gload = [&](int qb0) {
+    tile_gload<32>(qb, P.ldq, qb0, P.Lq, tid, qr);
+    tile_gload<32>(dob, P.lddo, qb0, P.Lq, tid, dor);
+    if (tid < 32) {
+      const int q = qb0 + tid;
+      st_l = q < P.Lq ? lse[q] : 0.f;
+      st_d = q < P.Lq ? dlt[q] : 0.f;
+    }
+  };
+  auto lstore = [&](int buf) {
+    tile_lstore<32>(&lds[buf][0][0], tid, qr);
+    tile_lstore<32>(&lds[buf][1][0], tid, dor);
+    if (tid < 32) { lstat[buf][0][tid] = st_l; lstat[buf][1][tid] = st_d; }
+  };
+  if (nblk > 0) { gload(qstart); lstore(0); }
+  __syncthreads();
+  const unsigned long long drop_base = ((unsigned long long)(b * P.H + h)) * P.Lq;
+
+  for (int it = 0; it < nblk; ++it) {
+    const int cur = it & 1, qb0 = qstart + it * 32;
+    if (it + 1 < nblk) gload(qb0 + 32);
+    const unsigned char* lq = &lds[cur][0][0];
+    const unsigned char* ldo_ = &lds[cur][1][0];
+    bf16x8 pdB[2], dsB[2];  // per key tile: B operands built from both query tiles
+    f32x4 pd[2][2], ds[2][2];  // [qt][nt]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      bf16x8 qa0 = *(const bf16x8*)(lq + (qt * 16 + fr) * KV_STRIDE + fg * 16);
+      bf16x8 qa1 = *(const bf16x8*)(lq + (qt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+      bf16x8 da0 = *(const bf16x8*)(ldo_ + (qt * 16 + fr) * KV_STRIDE + fg * 16);
+      bf16x8 da1 = *(const bf16x8*)(ldo_ + (qt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+      float lrow[4], drow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        lrow[r] = lstat[cur][0][qt * 16 + fg * 4 + r];
+        drow[r] = lstat[cur][1][qt * 16 + fg * 4 + r];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma16(qa0, kf[nt][0], s);
+        s = mfma16(qa1, kf[nt][1], s);
+        dp = mfma16(da0, vf[nt][0], dp);
+        dp = mfma16(da1, vf[nt][1], dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qb0 + qt * 16 + fg * 4 + r;
+          const bool valid = q < P.Lq && key[nt] < P.Lk && !(P.causal && key[nt] > q);
+          float p = valid ? __expf(s[r] - lrow[r]) : 0.f;
+          float keep = 1.f;
+          if (P.drop.thresh16) keep = attn_keep(P.drop, (drop_base + (unsigned long long)q) * P.Lk + key[nt]);
+          pd[qt][nt][r] = p * keep;
+          ds[qt][nt][r] = p * (dp[r] * keep - drow[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      pdB[nt] = pack8(pd[0][nt], pd[1][nt]);  // k-slot (g,j) <-> q = 16*(j>>2) + 4g + (j&3)
+      dsB[nt] = pack8(ds[0][nt], ds[1][nt]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int off = (fg * 4 + fq) * KV_STRIDE + (dt * 16 + fp * 4) * 2;
+      bf16x8 dot_ = cat8(lds_tr16(ldo_ + off), lds_tr16(ldo_ + off + 16 * KV_STRIDE));
+      bf16x8 qt_ = cat8(lds_tr16(lq + off), lds_tr16(lq + off + 16 * KV_STRIDE));
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        dvT[nt][dt] = mfma16(dot_, pdB[nt], dvT[nt][dt]);
+        dkT[nt][dt] = mfma16(qt_, dsB[nt], dkT[nt][dt]);
+      }
+    }
+    if (it + 1 < nblk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    if (key[nt] >= P.Lk) continue;
+    bf16_t* dkrow = P.dk + ((size_t)b * P.Lk + key[nt]) * P.lddk + h * HD;
+    bf16_t* dvrow = P.dv + ((size_t)b * P.Lk + key[nt]) * P.lddv + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 a = dkT[nt][dt], c = dvT[nt][dt];
+      *(u32x2*)(dkrow + dt * 16 + fg * 4) = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+      *(u32x2*)(dvrow + dt * 16 + fg * 4) = u32x2{pack_bf2(c[0], c[1]), pack_bf2(c[2], c[3])};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dQ.  workgroup = 128 queries (wave = 32, query on the lane), loop over 64-key tiles
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * KV_STRIDE];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
+  const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+  const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
+  const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
+  const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
+  const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
+
+  bf16x8 qf[2][2], dof[2][2];
+  int qrow[2];
+  float lse_q[2], dlt_q[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qrow[qt] = q0 + wave * 32 + qt * 16 + fr;
+    const int r = min(qrow[qt], P.Lq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[qt][ks] = *(const bf16x8*)(qb + (size_t)r * P.ldq + ks * 32 + fg * 8);
+      dof[qt][ks] = *(const bf16x8*)(dob + (size_t)r * P.lddo + ks * 32 + fg * 8);
+    }
+    lse_q[qt] = P.lse[((size_t)b * P.H + h) * P.Lq + r];
+    dlt_q[qt] = P.delta[((size_t)b * P.H + h) * P.Lq + r];
+  }
+  f32x4 dqT[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dqT[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int n_kv = ceil_div(P.Lk, 64);
+  if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
+  u32x4 kr[2], vr[2];
+  tile_gload<64>(kb, P.ldk, 0, P.Lk, tid, kr);
+  tile_gload<64>(vb, P.ldv, 0, P.Lk, tid, vr);
+  tile_lstore<64>(&lds[0][0][0], tid, kr);
+  tile_lstore<64>(&lds[0][1][0], tid, vr);
+  __syncthreads();
+  const unsigned long long drop_base = ((unsigned long long)(b * P.H + h)) * P.Lq;
+
+  for (int j = 0; j < n_kv; ++j) {
+    const int cur = j & 1, kv0 = j * 64;
+    if (j + 1 < n_kv) {
+      tile_gload<64>(kb, P.ldk, kv0 + 64, P.Lk, tid, kr);
+      tile_gload<64>(vb, P.ldv, kv0 + 64, P.Lk, tid, vr);
+    }
+    const unsigned char* lk = &lds[cur][0][0];
+    const unsigned char* lv = &lds[cur][1][0];
+    f32x4 dsT[2][4];  // [qt][kt] : dS^T[key = kt*16+4g+r][q = fr]
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      bf16x8 ka0 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + fg * 16);
+      bf16x8 ka1 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+      bf16x8 va0 = *(const bf16x8*)(lv + (kt * 16 + fr) * KV_STRIDE + fg * 16);
+      bf16x8 va1 = *(const bf16x8*)(lv + (kt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma16(ka0, qf[qt][0], s);
+        s = mfma16(ka1, qf[qt][1], s);
+        dp = mfma16(va0, dof[qt][0], dp);
+        dp = mfma16(va1, dof[qt][1], dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + kt * 16 + fg * 4 + r;
+          const bool valid = key < P.Lk && !(P.causal && key > qrow[qt]);
+          const float p = valid ? __expf(s[r] - lse_q[qt]) : 0.f;
+          float keep = 1.f;
+          if (P.drop.thresh16) keep = attn_keep(P.drop, (drop_base + (unsigned long long)qrow[qt]) * P.Lk + key);
+          dsT[qt][kt][r] = p * (dp[r] * keep - dlt_q[qt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 db[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) db[qt] = pack8(dsT[qt][2 * ks], dsT[qt][2 * ks + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const unsigned char* a = lk + (ks * 32 + fg * 4 + fq) * KV_STRIDE + (dt * 16 + fp * 4) * 2;
+        bf16x8 kt_ = cat8(lds_tr16(a), lds_tr16(a + 16 * KV_STRIDE));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) dqT[qt][dt] = mfma16(kt_, db[qt], dqT[qt][dt]);
+      }
+    }
+    if (j + 1 < n_kv) {
+      tile_lstore<64>(&lds[cur ^ 1][0][0], tid, kr);
+      tile_lstore<64>(&lds[cur ^ 1][1][0], tid, vr);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    if (qrow[qt] >= P.Lq) continue;
+    bf16_t* row = P.dq + ((size_t)b * P.Lq + qrow[qt]) * P.lddq + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 a = dqT[qt][dt];
+      *(u32x2*)(row + dt * 16 + fg * 4) = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact-f32 attention (parity path): one workgroup per (query, head, batch)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                       int ldk, const float* __restrict__ v, int ldv,
+                                                       float* __restrict__ o, int ldo, float* __restrict__ lse, int H,
+                                                       int Lq, int Lk, int causal) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[Lk] | q[64] | red[8] | part[4][64]
+  float* sc = sm;
+  float* qs = sm + Lk;
+  float* red = qs + 64;
+  float* part = red + 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const float* qp = q + ((size_t)b * Lq + qi) * ldq + h * HD;
+  const float* kb = k + (size_t)b * Lk * ldk + h * HD;
+  const float* vb = v + (size_t)b * Lk * ldv + h * HD;
+  if (tid < 64) qs[tid] = qp[tid];
+  __syncthreads();
+  const int nk = causal ? min(Lk, qi + 1) : Lk;
+  float mx = -INFINITY;
+  for (int key = tid; key < nk; key += 256) {
+    const float* kr = kb + (size_t)key * ldk;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      f32x4 kv = *(const f32x4*)(kr + d);
+      s = fmaf(qs[d], kv.x, s); s = fmaf(qs[d + 1], kv.y, s); s = fmaf(qs[d + 2], kv.z, s); s = fmaf(qs[d + 3], kv.w, s);
+    }
+    sc[key] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int key = tid; key < nk; key += 256) {
+    const float p = expf(sc[key] - mx);
+    sc[key] = p;
+    se += p;
+  }
+  se = wave_sum(se);
+  if (lane == 0) red[4 + wave] = se;
+  __syncthreads();
+  se = red[4] + red[5] + red[6] + red[7];
+  float acc = 0.f;
+  for (int key = wave; key < nk; key += 4) acc = fmaf(sc[key], vb[(size_t)key * ldv + lane], acc);
+  part[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (tid < 64) {
+    const float r = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    o[((size_t)b * Lq + qi) * ldo + h * HD + tid] = r / se;
+  }
+  if (tid == 0 && lse) lse[((size_t)b * H + h) * Lq + qi] = mx + logf(se);
+}
+
+extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
+                              int ldo, float* lse, int B, int H, int Lq, int Lk, int causal, int dtype, float p_drop,
+                              uint64_t seed, uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(q && k && v && o, "attn_fwd: null pointer");
+  MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_fwd: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MRMT3_F32) {
+    MR_CHECK_ARG(p_drop == 0.f, "attn_fwd: the f32 parity kernel has no dropout");
+    MR_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "attn_fwd: f32 strides must be multiples of 4");
+    const size_t shm = (size_t)(Lk + 64 + 8 + 256) * sizeof(float);
+    MR_CHECK_ARG(shm <= 160 * 1024, "attn_fwd f32: Lk too large");
+    hipLaunchKernelGGL(attn_f32_kernel, dim3(Lq, H, B), dim3(256), shm, s, (const float*)q, ldq, (const float*)k, ldk,
+                       (const float*)v, ldv, (float*)o, ldo, lse, H, Lq, Lk, causal);
+    MR_CHECK_LAUNCH("attn_fwd f32");
+    return MRMT3_OK;
+  }
+  MR_CHECK_ARG(dtype == MRMT3_BF16, "attn_fwd: unknown dtype");
+  MR_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attn_fwd: bf16 strides must be multiples of 8");
+  AttnParams P;
+  memset(&P, 0, sizeof(P));
+  P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.out = (bf16_t*)o; P.lse = lse;
+  P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
+  P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
+  P.drop = make_attn_drop(p_drop, seed, stream_id);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(256), 0, s, P);
+  MR_CHECK_LAUNCH("attn_fwd");
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                              int ldo, const void* d_o, int lddo, const float* lse, float* delta, void* dq, int lddq,
+                              void* dk, int lddk, void* dv, int lddv, int B, int H, int Lq, int Lk, int causal,
+                              float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
+  MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_bwd: bad sizes");
+  MR_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
+                   lddv % 4 == 0, "attn_bwd: strides must be multiples of 8 (inputs) / 4 (outputs)");
+  AttnParams P;
+  memset(&P, 0, sizeof(P));
+  P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.o = (const bf16_t*)o;
+  P.d_o = (const bf16_t*)d_o; P.lse = (float*)lse; P.delta = delta;
+  P.dq = (bf16_t*)dq; P.dk = (bf16_t*)dk; P.dv = (bf16_t*)dv;
+  P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo; P.lddo = lddo; P.lddq = lddq; P.lddk = lddk; P.lddv = lddv;
+  P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
+  P.drop = make_attn_drop(p_drop, seed, stream_id);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ceil_div(B * Lq, 4)), dim3(256), 0, s, P);
+  MR_CHECK_LAUNCH("attn_bwd delta");
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(ceil_div(Lk, 128), H, B), dim3(256), 0, s, P);
+  MR_CHECK_LAUNCH("attn_bwd dkdv");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(256), 0, s, P);
+  MR_CHECK_LAUNCH("attn_bwd dq");
+  return MRMT3_OK;
+}

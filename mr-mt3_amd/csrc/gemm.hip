@@ -1,0 +1,353 @@
+// K2/K4/K6/K7/K9/K10 — bias-free Linear layers on gfx950 MFMA.
+//
+// Stands for every nn.Linear(bias=False) in the reference's T5 stack (HF T5Attention q/k/v/o,
+// T5DenseGatedGeluDense wi_0/wi_1/wo, models/t5.py:51 proj, :72 lm_head) and their autograd
+// backward.  Three products cover forward, dgrad and wgrad:
+//   NT  C[M,N]   = A[M,K]  . B[N,K]^T     y = x W^T ; dx = dy (W^T)^T with W^T kept pre-transposed
+//   TN  C[N1,N2] = A[M,N1]^T . B[M,N2]    dW = dy^T x, reduction over the M (token) rows
+//
+// NT kernel: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4
+// v_mfma_f32_16x16x32_bf16 tiles), K step = 128 bytes of each row (64 bf16 / 32 f32), operands
+// staged global -> registers -> LDS (issue-early / write-late), double-buffered, one barrier per
+// K step.  LDS rows are 128 B with the 16-B chunk index XOR-ed by (row & 7): ds_read_b128 fragment
+// reads are conflict-free.  Workgroup ids are remapped so the 8 XCDs each walk a contiguous run of
+// (m-tile, n-tile) pairs and an A row-panel stays in one XCD's L2.
+// f32 inputs use v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) on the same LDS image.
+//
+// TN kernel: 128x128 tile of dW per workgroup, 64 token rows per step; operand tiles are stored
+// row-major [64][128] with a 288-B row stride and consumed through ds_read_b64_tr_b16 (hardware
+// transpose) so both MFMA operands get their 8 consecutive reduction indices per lane; the token
+// range is split over workgroups into f32 slabs that a second kernel sums in a fixed order
+// (bitwise reproducible, no atomics).
+#include "common.h"
+
+#define TILE 128
+#define ROWB 128  // bytes per LDS row
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective remap: blocks with equal bid%8 share an XCD (observed round-robin dispatch; only a
+  // speed assumption).  Give each XCD a contiguous chunk of the logical tile order.
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + slot;
+}
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+__device__ __forceinline__ f32x4 mfma_step(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_step(f32x4 a, f32x4 b, f32x4 c) {
+  // 16 k-values per fragment pair: lane group g holds k = 4g..4g+3; MFMA s pairs element s of
+  // every lane (k-slot g <-> k = 4g+s) — A and B use the same permutation.
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  return c;
+}
+
+template <typename TIN, typename TOUT, bool ACCUM>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
+                                                         const TIN* __restrict__ B, int ldb,
+                                                         TOUT* __restrict__ C, int ldc, int M, int N,
+                                                         int K, int tiles_n) {
+  constexpr int EPC = 16 / sizeof(TIN);    // elements per 16-B chunk
+  constexpr int BK = ROWB / sizeof(TIN);   // elements per K step
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TILE * ROWB];  // [buf][A|B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = gridDim.x;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (t / tiles_n) * TILE, n0 = (t % tiles_n) * TILE;
+
+  // staging map: 4 chunks per thread per operand
+  int srow[4], schunk[4];
+  const TIN* ga[4];
+  const TIN* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int q = tid + 256 * i;
+    srow[i] = q >> 3;
+    schunk[i] = q & 7;
+    int ra = min(m0 + srow[i], M - 1), rb = min(n0 + srow[i], N - 1);
+    ga[i] = A + (size_t)ra * lda + schunk[i] * EPC;
+    gb[i] = B + (size_t)rb * ldb + schunk[i] * EPC;
+  }
+  u32x4 ra_[4], rb_[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra_[i] = *(const u32x4*)(ga[i] + k0);
+      rb_[i] = *(const u32x4*)(gb[i] + k0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = srow[i] * ROWB + ((schunk[i] ^ (srow[i] & 7)) << 4);
+      *(u32x4*)(&lds[buf][0][off]) = ra_[i];
+      *(u32x4*)(&lds[buf][1][off]) = rb_[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nk = K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const unsigned char* la = &lds[cur][0][0];
+    const unsigned char* lb = &lds[cur][1][0];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename Frag<TIN>::type af[4], bfr[4];
+      const int c = ks * 4 + fg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int rowa = wr * 64 + i * 16 + fr;
+        int rowb = wc * 64 + i * 16 + fr;
+        af[i] = *(const typename Frag<TIN>::type*)(la + rowa * ROWB + ((c ^ (rowa & 7)) << 4));
+        bfr[i] = *(const typename Frag<TIN>::type*)(lb + rowb * ROWB + ((c ^ (rowb & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds C[row = ..+fg*4+r][col = ..+fr]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wr * 64 + i * 16 + fg * 4 + r;
+      if (row >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wc * 64 + j * 16 + fr;
+        if (col >= N) continue;
+        float v = acc[i][j][r];
+        TOUT* p = C + (size_t)row * ldc + col;
+        if constexpr (sizeof(TOUT) == 2) {
+          *p = f2bf(v);
+        } else {
+          if (ACCUM) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename TIN, typename TOUT, bool ACCUM>
+static int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     hipStream_t s) {
+  const int tiles_m = ceil_div(M, TILE), tiles_n = ceil_div(N, TILE);
+  dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
+  hipLaunchKernelGGL((gemm_nt_kernel<TIN, TOUT, ACCUM>), grid, block, 0, s, (const TIN*)A, lda, (const TIN*)B, ldb,
+                     (TOUT*)C, ldc, M, N, K, tiles_n);
+  MR_CHECK_LAUNCH("gemm_nt");
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
+                             int K, int in_dtype, int out_dtype, int accumulate, void* stream) {
+  MR_CHECK_ARG(A && B && C, "gemm_nt: null pointer");
+  MR_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%d N=%d K=%d", M, N, K);
+  const int esz = in_dtype == MRMT3_BF16 ? 2 : 4;
+  MR_CHECK_ARG((K * esz) % ROWB == 0, "gemm_nt: K*elem_size must be a multiple of 128 bytes (K=%d)", K);
+  MR_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "gemm_nt: row strides must be 16-byte multiples");
+  MR_CHECK_ARG(!(accumulate && out_dtype != MRMT3_F32), "gemm_nt: accumulate needs f32 output");
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == MRMT3_BF16) {
+    if (out_dtype == MRMT3_BF16) return launch_nt<bf16_t, bf16_t, false>(A, lda, B, ldb, C, ldc, M, N, K, s);
+    if (accumulate) return launch_nt<bf16_t, float, true>(A, lda, B, ldb, C, ldc, M, N, K, s);
+    return launch_nt<bf16_t, float, false>(A, lda, B, ldb, C, ldc, M, N, K, s);
+  } else if (in_dtype == MRMT3_F32) {
+    MR_CHECK_ARG(out_dtype == MRMT3_F32, "gemm_nt: f32 inputs need f32 output");
+    if (accumulate) return launch_nt<float, float, true>(A, lda, B, ldb, C, ldc, M, N, K, s);
+    return launch_nt<float, float, false>(A, lda, B, ldb, C, ldc, M, N, K, s);
+  }
+  mrmt3_set_error("gemm_nt: unknown dtype %d", in_dtype);
+  return MRMT3_ERR_INVALID_ARG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: C[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (bf16 in, f32 out)
+// ------------------------------------------------------------------------------------------------
+#define TN_ROWS 64    // token rows per step
+#define TN_STRIDE 288  // bytes per LDS row: 128 bf16 + 32 B pad (8 consecutive rows -> disjoint banks)
+
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
+                                                         const bf16_t* __restrict__ B, int ldb,
+                                                         float* __restrict__ slab, int M, int N1, int N2,
+                                                         int tiles_n2, int n_tiles, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TN_ROWS * TN_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile = blockIdx.x % n_tiles, split = blockIdx.x / n_tiles;
+  const int a0 = (tile / tiles_n2) * TILE, b0 = (tile % tiles_n2) * TILE;
+  const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+
+  // staging: tile is 64 rows x 16 chunks(16 B) = 1024 chunks per operand -> 4 per thread
+  int srow[4], schunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int q = tid + 256 * i;
+    srow[i] = q >> 4;
+    schunk[i] = q & 15;
+  }
+  u32x4 ra_[4], rb_[4];
+  auto gload = [&](int mrow0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mrow0 + srow[i];
+      const int ca = min(a0 + schunk[i] * 8, N1 - 8), cb = min(b0 + schunk[i] * 8, N2 - 8);
+      if (m < mend) {
+        ra_[i] = *(const u32x4*)(A + (size_t)m * lda + ca);
+        rb_[i] = *(const u32x4*)(B + (size_t)m * ldb + cb);
+      } else {
+        ra_[i] = {0u, 0u, 0u, 0u};
+        rb_[i] = {0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = srow[i] * TN_STRIDE + (schunk[i] << 4);
+      *(u32x4*)(&lds[buf][0][off]) = ra_[i];
+      *(u32x4*)(&lds[buf][1][off]) = rb_[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addressing: 16-lane group g, lane = 4*q+p inside the group supplies the
+  // address of row (4g+q) [+16 for the second half of the k-slots], columns 4p..4p+3
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  const int nsteps = ceil_div(max(mend - mbeg, 0), TN_ROWS);
+  if (nsteps > 0) {
+    gload(mbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) gload(mbeg + (st + 1) * TN_ROWS);
+    const unsigned char* la = &lds[cur][0][0];
+    const unsigned char* lb = &lds[cur][1][0];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int rbase = ks * 32 + fg * 4 + fq;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cola = (wr * 64 + i * 16 + fp * 4) * 2, colb = (wc * 64 + i * 16 + fp * 4) * 2;
+        s16x4 a_lo = lds_tr16(la + rbase * TN_STRIDE + cola);
+        s16x4 a_hi = lds_tr16(la + (rbase + 16) * TN_STRIDE + cola);
+        s16x4 b_lo = lds_tr16(lb + rbase * TN_STRIDE + colb);
+        s16x4 b_hi = lds_tr16(lb + (rbase + 16) * TN_STRIDE + colb);
+        af[i] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+        bfr[i] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+    }
+    if (st + 1 < nsteps) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = slab + (size_t)split * N1 * N2;
+  const int fr = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = a0 + wr * 64 + i * 16 + fg * 4 + r;
+      if (row >= N1) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = b0 + wc * 64 + j * 16 + fr;
+        if (col < N2) out[(size_t)row * N2 + col] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int ldc, int N1, int N2,
+                                   int splits, int accumulate) {
+  const size_t n = (size_t)N1 * N2;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+       i += (size_t)gridDim.x * blockDim.x * 4) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) s += *(const f32x4*)(slab + (size_t)k * n + i);
+    const int row = (int)(i / N2), col = (int)(i % N2);
+    float* p = C + (size_t)row * ldc + col;
+    if (accumulate) s += *(const f32x4*)p;
+    *(f32x4*)p = s;
+  }
+}
+
+static void tn_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per_split) {
+  const int t = ceil_div(N1, TILE) * ceil_div(N2, TILE);
+  const int steps = ceil_div(M, TN_ROWS);
+  int s = ceil_div(1024, t);              // aim for ~4 workgroups per CU
+  s = s < 1 ? 1 : s;
+  const int max_s = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps (512 rows) per split
+  if (s > max_s) s = max_s;
+  int rps = ceil_div(steps, s) * TN_ROWS;
+  s = ceil_div(M, rps);
+  *tiles = t; *splits = s; *rows_per_split = rps;
+}
+
+extern "C" size_t mrmt3_gemm_tn_workspace_bytes(int M, int N1, int N2) {
+  int t, s, r;
+  tn_plan(M, N1, N2, &t, &s, &r);
+  return (size_t)s * N1 * N2 * sizeof(float);
+}
+
+extern "C" int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1,
+                             int N2, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  MR_CHECK_ARG(A && B && C && workspace, "gemm_tn: null pointer");
+  MR_CHECK_ARG(M > 0 && N1 >= 8 && N2 >= 8, "gemm_tn: bad sizes");
+  MR_CHECK_ARG(N1 % 8 == 0 && N2 % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0,
+               "gemm_tn: N1/lda/ldb must be multiples of 8, N2/ldc of 4");
+  int tiles, splits, rps;
+  tn_plan(M, N1, N2, &tiles, &splits, &rps);
+  MR_CHECK_ARG(workspace_bytes >= (size_t)splits * N1 * N2 * sizeof(float), "gemm_tn: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, (float*)workspace, M, N1, N2, ceil_div(N2, TILE), tiles, rps);
+  MR_CHECK_LAUNCH("gemm_tn");
+  const size_t n = (size_t)N1 * N2;
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, C, ldc,
+                     N1, N2, splits, accumulate);
+  MR_CHECK_LAUNCH("gemm_tn reduce");
+  return MRMT3_OK;
+}

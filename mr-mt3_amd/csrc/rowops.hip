@@ -1,0 +1,699 @@
+// K3 / K7 / K8 / K9 / K11 — the HBM-bound row and element-wise kernels of the T5 block:
+// fused residual-add + dropout + T5LayerNorm (RMS), gated-GELU, embedding gather / scatter-add,
+// sinusoid add, cross-entropy, AdamW, cast / transpose helpers.
+//
+// All of them stream their rows once with 16-byte accesses (float4 / 8 x bf16 per lane), keep the
+// row statistics in fp32 and reduce with 64-lane wave shuffles.  Reference lines are cited at each
+// entry point.
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+  f32x4 t = *(const f32x4*)p;
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float v[4]) {
+  u32x2 t = *(const u32x2*)p;
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+  *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
+  *(u32x2*)p = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused add + dropout + RMS norm, forward.   one wave per row, 4 rows per workgroup
+// HF T5LayerNorm: w * (x * rsqrt(mean(x^2) + eps)), fp32 statistics.
+// ------------------------------------------------------------------------------------------------
+#define NORM_MAXV 8  // float4 groups per lane: cols <= 64*4*8 = 2048
+
+template <typename TY, typename TN, int NV>
+__global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const float* __restrict__ x0, const TY* __restrict__ y,
+                                                              const float* __restrict__ w, float eps,
+                                                              float* __restrict__ x1, TN* __restrict__ xn,
+                                                              float* __restrict__ rstd_out, int rows, int cols,
+                                                              DropCfg dy, DropCfg dout, int out_drop) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int nv = NV;  // float4 groups per lane (cols = NV*256)
+  float v[NV][4];
+  float ss = 0.f;
+  const size_t base = (size_t)row * cols;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i < nv) {
+      const int col = i * 256 + lane * 4;
+      load4<float>(x0 + base + col, v[i]);
+      if (y != nullptr) {
+        float yv[4];
+        load4<TY>(y + base + col, yv);
+        if (dy.thresh) {
+          float m[4];
+          drop_mask4(dy, (base + col) >> 2, m);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yv[e] *= m[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += yv[e];
+      }
+      if (x1 != nullptr) store4<float>(x1 + base + col, v[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)cols + eps);
+  if (lane == 0 && rstd_out != nullptr) rstd_out[row] = rstd;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i < nv) {
+      const int col = i * 256 + lane * 4;
+      float wv[4], o[4];
+      load4<float>(w + col, wv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = wv[e] * (v[i][e] * rstd);
+      if (out_drop && dout.thresh) {
+        float m[4];
+        drop_mask4(dout, (base + col) >> 2, m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] *= m[e];
+      }
+      store4<TN>(xn + base + col, o);
+    }
+  }
+}
+
+extern "C" int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const float* w, float eps,
+                                     float* x1, void* xn, int xn_dtype, float* rstd, int rows, int cols,
+                                     float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                                     int out_drop, void* stream) {
+  MR_CHECK_ARG(x0 && w && xn, "add_rmsnorm_fwd: null pointer");
+  MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
+               "add_rmsnorm_fwd: cols must be 256, 512, 1024 or 2048");
+  DropCfg dy = make_drop(p_drop, seed, stream_y), dn = make_drop(p_drop, seed, stream_out);
+  dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH2(TY, TN, NV)                                                                                 \
+  hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<TY, TN, NV>), grid, block, 0, s, x0, (const TY*)y, w, eps, x1, \
+                     (TN*)xn, rstd, rows, cols, dy, dn, out_drop)
+#define LAUNCH(TY, TN)                                                          \
+  do {                                                                          \
+    if (cols == 512) LAUNCH2(TY, TN, 2);                                        \
+    else if (cols == 256) LAUNCH2(TY, TN, 1);                                   \
+    else if (cols == 1024) LAUNCH2(TY, TN, 4);                                  \
+    else LAUNCH2(TY, TN, 8);                                                    \
+  } while (0)
+  if (y_dtype == MRMT3_BF16 && xn_dtype == MRMT3_BF16) LAUNCH(bf16_t, bf16_t);
+  else if (y_dtype == MRMT3_F32 && xn_dtype == MRMT3_BF16) LAUNCH(float, bf16_t);
+  else if (y_dtype == MRMT3_BF16 && xn_dtype == MRMT3_F32) LAUNCH(bf16_t, float);
+  else LAUNCH(float, float);
+#undef LAUNCH
+#undef LAUNCH2
+  MR_CHECK_LAUNCH("add_rmsnorm_fwd");
+  return MRMT3_OK;
+}
+
+// backward: each workgroup owns NB_ROWS consecutive rows (wave w takes rows w, w+4, ...), keeps the
+// per-column dw partial sums in registers and issues one f32 atomic per column at the end.
+#define NB_ROWS 32
+template <int NV>
+__global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ dres,
+                                                              const float* __restrict__ x1, const float* __restrict__ rstd_in,
+                                                              const float* __restrict__ w, float* __restrict__ dx1,
+                                                              bf16_t* __restrict__ dy, float* __restrict__ dw, int rows,
+                                                              int cols, DropCfg ddy, DropCfg dout, int out_drop) {
+  __shared__ float red[4 * 256 * NV];  // [wave][col]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int nv = NV;
+  float dwp[NV][4];
+  float wv[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dwp[i][e] = 0.f;
+    if (i < nv) load4<float>(w + i * 256 + lane * 4, wv[i]);
+  }
+  const int row_end = min(rows, (int)(blockIdx.x + 1) * NB_ROWS);
+  for (int row = blockIdx.x * NB_ROWS + wave; row < row_end; row += 4) {
+    const size_t base = (size_t)row * cols;
+    const float rstd = rstd_in[row];
+    float g[NV][4], xh[NV][4];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i < nv) {
+        const int col = i * 256 + lane * 4;
+        load4<float>(dxn + base + col, g[i]);
+        if (out_drop && dout.thresh) {
+          float m[4];
+          drop_mask4(dout, (base + col) >> 2, m);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[i][e] *= m[e];
+        }
+        load4<float>(x1 + base + col, xh[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] *= rstd;
+          dwp[i][e] += g[i][e] * xh[i][e];
+          g[i][e] *= wv[i][e];
+          dot += g[i][e] * xh[i][e];
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i < nv) {
+        const int col = i * 256 + lane * 4;
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = rstd * (g[i][e] - xh[i][e] * dot);
+        if (dres != nullptr) {
+          float r[4];
+          load4<float>(dres + base + col, r);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] += r[e];
+        }
+        store4<float>(dx1 + base + col, d);
+        if (dy != nullptr) {
+          if (ddy.thresh) {
+            float m[4];
+            drop_mask4(ddy, (base + col) >> 2, m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] *= m[e];
+          }
+          store4<bf16_t>(dy + base + col, d);
+        }
+      }
+    }
+  }
+  // reduce dw partials across the 4 waves, then one atomic per column
+  float* redf = &red[0];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) redf[wave * cols + i * 256 + lane * 4 + e] = dwp[i][e];
+    }
+  __syncthreads();
+  if (dw != nullptr)
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      float s = redf[c] + redf[cols + c] + redf[2 * cols + c] + redf[3 * cols + c];
+      atomicAdd(dw + c, s);
+    }
+}
+
+extern "C" int mrmt3_add_rmsnorm_bwd(const float* dxn, const float* dres, const float* x1, const float* rstd,
+                                     const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
+                                     float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                                     int out_drop, void* stream) {
+  MR_CHECK_ARG(dxn && x1 && rstd && w && dx1, "add_rmsnorm_bwd: null pointer");
+  MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
+               "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
+  DropCfg dy = make_drop(p_drop, seed, stream_y), dn = make_drop(p_drop, seed, stream_out);
+#define LAUNCH(NV)                                                                                             \
+  hipLaunchKernelGGL(add_rmsnorm_bwd_kernel<NV>, dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0,        \
+                     (hipStream_t)stream, dxn, dres, x1, rstd, w, dx1, (bf16_t*)dy_bf16, dw, rows, cols, dy, dn, \
+                     out_drop)
+  if (cols == 512) LAUNCH(2);
+  else if (cols == 256) LAUNCH(1);
+  else if (cols == 1024) LAUNCH(4);
+  else LAUNCH(8);
+#undef LAUNCH
+  MR_CHECK_LAUNCH("add_rmsnorm_bwd");
+  return MRMT3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gated GELU (HF T5DenseGatedGeluDense + NewGELUActivation)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_new_f(float x) {
+  const float c = 0.7978845608028654f;  // sqrt(2/pi)
+  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * (x * x * x))));
+}
+__device__ __forceinline__ void gelu_new_fd(float x, float* f, float* d) {
+  const float c = 0.7978845608028654f;
+  const float t = tanhf(c * (x + 0.044715f * (x * x * x)));
+  *f = 0.5f * x * (1.0f + t);
+  *d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+template <typename T>
+__global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ g, int rows, int dff, DropCfg d) {
+  const size_t n4 = (size_t)rows * dff / 4;
+  const int dff4 = dff / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / dff4;
+    const int col = (int)(i % dff4) * 4;
+    float a[4], b[4], o[4];
+    load4<T>(h + row * 2 * dff + col, a);
+    load4<T>(h + row * 2 * dff + dff + col, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gelu_new_f(a[e]) * b[e];
+    if (d.thresh) {
+      float m[4];
+      drop_mask4(d, i, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] *= m[e];
+    }
+    store4<T>(g + row * dff + col, o);
+  }
+}
+
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ dg, bf16_t* __restrict__ dh,
+                                 int rows, int dff, DropCfg d) {
+  const size_t n4 = (size_t)rows * dff / 4;
+  const int dff4 = dff / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / dff4;
+    const int col = (int)(i % dff4) * 4;
+    float a[4], b[4], go[4], da[4], db[4];
+    load4<bf16_t>(h + row * 2 * dff + col, a);
+    load4<bf16_t>(h + row * 2 * dff + dff + col, b);
+    load4<bf16_t>(dg + row * dff + col, go);
+    if (d.thresh) {
+      float m[4];
+      drop_mask4(d, i, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) go[e] *= m[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float f, fd;
+      gelu_new_fd(a[e], &f, &fd);
+      da[e] = go[e] * b[e] * fd;
+      db[e] = go[e] * f;
+    }
+    store4<bf16_t>(dh + row * 2 * dff + col, da);
+    store4<bf16_t>(dh + row * 2 * dff + dff + col, db);
+  }
+}
+
+static inline int ew_blocks(size_t n_items) {
+  size_t b = (n_items + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop, uint64_t seed,
+                               uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(h && g && rows > 0 && dff % 4 == 0, "geglu_fwd: bad args");
+  DropCfg d = make_drop(p_drop, seed, stream_id);
+  const int blocks = ew_blocks((size_t)rows * dff / 4);
+  if (dtype == MRMT3_BF16)
+    hipLaunchKernelGGL(geglu_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                       (bf16_t*)g, rows, dff, d);
+  else
+    hipLaunchKernelGGL(geglu_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)h,
+                       (float*)g, rows, dff, d);
+  MR_CHECK_LAUNCH("geglu_fwd");
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
+                               uint64_t seed, uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(h && dg && dh && rows > 0 && dff % 4 == 0, "geglu_bwd: bad args");
+  DropCfg d = make_drop(p_drop, seed, stream_id);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks((size_t)rows * dff / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)h, (const bf16_t*)dg, (bf16_t*)dh, rows, dff, d);
+  MR_CHECK_LAUNCH("geglu_bwd");
+  return MRMT3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding gather (+ _shift_right) + sinusoid add + dropout; scatter-add backward
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t token_at(const int64_t* ids, int row, int seq_len, int shift, int start_id,
+                                            int pad_id, int vocab) {
+  int64_t id;
+  if (shift) {
+    const int t = row % seq_len;
+    id = (t == 0) ? start_id : ids[row - 1];
+    if (id == -100) id = pad_id;
+  } else {
+    id = ids[row];
+  }
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  return id;
+}
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                        const float* __restrict__ pos, float* __restrict__ x, int rows,
+                                                        int seq_len, int d, int vocab, int shift, int start_id,
+                                                        int pad_id, int pos_offset, DropCfg dc) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t id = token_at(ids, row, seq_len, shift, start_id, pad_id, vocab);
+  const float* trow = table + (size_t)id * d;
+  const float* prow = pos + (size_t)((row % seq_len) + pos_offset) * d;
+  const size_t base = (size_t)row * d;
+  for (int col = lane * 4; col < d; col += 256) {
+    float a[4], p[4];
+    load4<float>(trow + col, a);
+    load4<float>(prow + col, p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += p[e];
+    if (dc.thresh) {
+      float m[4];
+      drop_mask4(dc, (base + col) >> 2, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= m[e];
+    }
+    store4<float>(x + base + col, a);
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
+                                                        float* __restrict__ dtable, int rows, int seq_len, int d,
+                                                        int vocab, int shift, int start_id, int pad_id, DropCfg dc) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t id = token_at(ids, row, seq_len, shift, start_id, pad_id, vocab);
+  float* trow = dtable + (size_t)id * d;
+  const size_t base = (size_t)row * d;
+  for (int col = lane * 4; col < d; col += 256) {
+    float a[4];
+    load4<float>(dx + base + col, a);
+    if (dc.thresh) {
+      float m[4];
+      drop_mask4(dc, (base + col) >> 2, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= m[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(trow + col + e, a[e]);
+  }
+}
+
+extern "C" int mrmt3_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* x, int rows,
+                               int seq_len, int d, int vocab, int shift, int start_id, int pad_id, int pos_offset,
+                               float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(ids && table && pos && x && rows > 0 && seq_len > 0 && d % 4 == 0, "embed_fwd: bad args");
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids,
+                     table, pos, x, rows, seq_len, d, vocab, shift, start_id, pad_id, pos_offset,
+                     make_drop(p_drop, seed, stream_id));
+  MR_CHECK_LAUNCH("embed_fwd");
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtable, int rows, int seq_len, int d,
+                               int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed,
+                               uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(ids && dx && dtable && rows > 0 && seq_len > 0 && d % 4 == 0, "embed_bwd: bad args");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids, dx,
+                     dtable, rows, seq_len, d, vocab, shift, start_id, pad_id, make_drop(p_drop, seed, stream_id));
+  MR_CHECK_LAUNCH("embed_bwd");
+  return MRMT3_OK;
+}
+
+template <typename T>
+__global__ void addpos_fwd_kernel(const T* __restrict__ src, const float* __restrict__ pos, float* __restrict__ x,
+                                  size_t n4, int seq_len, int d, int pos_offset, DropCfg dc) {
+  const int d4 = d / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / d4;
+    const int col = (int)(i % d4) * 4;
+    float a[4], p[4];
+    load4<T>(src + i * 4, a);
+    load4<float>(pos + (size_t)((row % seq_len) + pos_offset) * d + col, p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += p[e];
+    if (dc.thresh) {
+      float m[4];
+      drop_mask4(dc, i, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= m[e];
+    }
+    store4<float>(x + i * 4, a);
+  }
+}
+
+extern "C" int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos, float* x, int rows, int seq_len,
+                                int d, int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id,
+                                void* stream) {
+  MR_CHECK_ARG(src && pos && x && rows > 0 && seq_len > 0 && d % 4 == 0, "addpos_fwd: bad args");
+  const size_t n4 = (size_t)rows * d / 4;
+  DropCfg dc = make_drop(p_drop, seed, stream_id);
+  if (src_dtype == MRMT3_BF16)
+    hipLaunchKernelGGL(addpos_fwd_kernel<bf16_t>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, pos, x, n4, seq_len, d, pos_offset, dc);
+  else
+    hipLaunchKernelGGL(addpos_fwd_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, pos, x, n4, seq_len, d, pos_offset, dc);
+  MR_CHECK_LAUNCH("addpos_fwd");
+  return MRMT3_OK;
+}
+
+__global__ void dropmask_cast_kernel(const float* __restrict__ dx, bf16_t* __restrict__ out, size_t n4, DropCfg dc) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float a[4];
+    load4<float>(dx + i * 4, a);
+    if (dc.thresh) {
+      float m[4];
+      drop_mask4(dc, i, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] *= m[e];
+    }
+    store4<bf16_t>(out + i * 4, a);
+  }
+}
+
+extern "C" int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed,
+                                   uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(dx && out_bf16 && n % 4 == 0, "dropmask_cast: bad args");
+  hipLaunchKernelGGL(dropmask_cast_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dx,
+                     (bf16_t*)out_bf16, n / 4, make_drop(p_drop, seed, stream_id));
+  MR_CHECK_LAUNCH("dropmask_cast");
+  return MRMT3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-entropy (tasks/mt3_net.py:32-35; weighted variant tasks/mt3_net.py:96-108)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ce_weights(int64_t t, int weighted, int lo, int hi, float* w, float* n) {
+  if (t == -100) { *w = 0.f; *n = 0.f; return; }
+  if (weighted && t >= lo && t <= hi) { *w = 3.f; *n = 2.f; return; }
+  *w = 1.f; *n = 1.f;
+}
+
+__global__ void ce_count_kernel(const int64_t* __restrict__ targets, int rows, int weighted, int lo, int hi,
+                                float* __restrict__ denom) {
+  float s = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+    float w, n;
+    ce_weights(targets[i], weighted, lo, hi, &w, &n);
+    s += n;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(denom, s);
+}
+
+extern "C" int mrmt3_ce_count(const int64_t* targets, int rows, int weighted, int inst_lo, int inst_hi,
+                              float* denom_dev, void* stream) {
+  MR_CHECK_ARG(targets && denom_dev && rows > 0, "ce_count: bad args");
+  int blocks = ceil_div(rows, 256);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(ce_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, targets, rows, weighted,
+                     inst_lo, inst_hi, denom_dev);
+  MR_CHECK_LAUNCH("ce_count");
+  return MRMT3_OK;
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                 const float* __restrict__ denom, float* __restrict__ loss,
+                                                 TD* __restrict__ dlogits, int rows, int V, int weighted, int lo,
+                                                 int hi, float grad_scale) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* lp = logits + (size_t)row * V;
+  const int64_t t = targets[row];
+  float w, n;
+  ce_weights(t, weighted, lo, hi, &w, &n);
+  TD* dp = dlogits ? dlogits + (size_t)row * V : nullptr;
+  if (w == 0.f) {
+    if (dp) for (int c = tid * 4; c < V; c += 1024) { float z[4] = {0.f, 0.f, 0.f, 0.f}; store4<TD>(dp + c, z); }
+    return;
+  }
+  float mx = -INFINITY;
+  for (int c = tid * 4; c < V; c += 1024) {
+    float v[4];
+    load4<float>(lp + c, v);
+    mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int c = tid * 4; c < V; c += 1024) {
+    float v[4];
+    load4<float>(lp + c, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) se += expf(v[e] - mx);
+  }
+  se = wave_sum(se);
+  if (lane == 0) red[4 + wave] = se;
+  __syncthreads();
+  se = red[4] + red[5] + red[6] + red[7];
+  const float lse = mx + logf(se);
+  const float inv_den = 1.f / denom[0];
+  if (tid == 0) atomicAdd(loss, w * (lse - lp[t]) * inv_den);
+  if (dp) {
+    const float gs = w * inv_den * grad_scale;
+    for (int c = tid * 4; c < V; c += 1024) {
+      float v[4];
+      load4<float>(lp + c, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p = expf(v[e] - lse);
+        if (c + e == t) p -= 1.f;
+        v[e] = p * gs;
+      }
+      store4<TD>(dp + c, v);
+    }
+  }
+}
+
+extern "C" int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* denom_dev, float* loss_dev,
+                                void* dlogits, int dl_dtype, int rows, int V, int weighted, int inst_lo,
+                                int inst_hi, float grad_scale, void* stream) {
+  MR_CHECK_ARG(logits && targets && denom_dev && loss_dev && rows > 0 && V % 4 == 0, "ce_fwd_bwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (dl_dtype == MRMT3_BF16)
+    hipLaunchKernelGGL(ce_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, logits, targets, denom_dev, loss_dev,
+                       (bf16_t*)dlogits, rows, V, weighted, inst_lo, inst_hi, grad_scale);
+  else
+    hipLaunchKernelGGL(ce_kernel<float>, dim3(rows), dim3(256), 0, s, logits, targets, denom_dev, loss_dev,
+                       (float*)dlogits, rows, V, weighted, inst_lo, inst_hi, grad_scale);
+  MR_CHECK_LAUNCH("ce_fwd_bwd");
+  return MRMT3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW over the flat parameter buffer (torch.optim.AdamW single-tensor semantics)
+// ------------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n4, const float* __restrict__ lr_dev,
+                             const int32_t* __restrict__ step_dev, float b1, float b2, float eps, float wd,
+                             float gscale, bf16_t* __restrict__ shadow) {
+  const float lr = lr_dev[0];
+  const int step = step_dev[0] + 1;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float decay = 1.f - lr * wd;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float pv[4], gv[4], mv[4], vv[4];
+    load4<float>(p + i * 4, pv);
+    load4<float>(g + i * 4, gv);
+    load4<float>(m + i * 4, mv);
+    load4<float>(v + i * 4, vv);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gv[e] * gscale;
+      pv[e] *= decay;
+      mv[e] = mv[e] + (gr - mv[e]) * (1.f - b1);           // exp_avg.lerp_(grad, 1-beta1)
+      vv[e] = vv[e] * b2 + (1.f - b2) * gr * gr;           // mul_(beta2).addcmul_(g, g, 1-beta2)
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pv[e] -= step_size * (mv[e] / denom);
+    }
+    store4<float>(p + i * 4, pv);
+    store4<float>(m + i * 4, mv);
+    store4<float>(v + i * 4, vv);
+    if (shadow) store4<bf16_t>(shadow + i * 4, pv);
+  }
+}
+__global__ void step_inc_kernel(int32_t* step) { step[0] += 1; }
+
+extern "C" int mrmt3_adamw_step(float* p, const float* g, float* m, float* v, size_t n, const float* lr_dev,
+                                int32_t* step_dev, float beta1, float beta2, float eps, float weight_decay,
+                                float grad_scale, void* shadow_bf16, void* stream) {
+  MR_CHECK_ARG(p && g && m && v && lr_dev && step_dev && n % 4 == 0, "adamw_step: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s, p, g, m, v, n / 4, lr_dev, step_dev,
+                     beta1, beta2, eps, weight_decay, grad_scale, (bf16_t*)shadow_bf16);
+  MR_CHECK_LAUNCH("adamw_step");
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  MR_CHECK_LAUNCH("adamw_step inc");
+  return MRMT3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cast / transpose helpers (bf16 shadow weights and their pre-transposed dgrad copies)
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float a[4];
+    load4<TI>(in + i * 4, a);
+    store4<TO>(out + i * 4, a);
+  }
+}
+
+extern "C" int mrmt3_cast(const void* in, int in_dtype, void* out, int out_dtype, size_t n, void* stream) {
+  MR_CHECK_ARG(in && out && n % 4 == 0, "cast: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int b = ew_blocks(n / 4);
+  if (in_dtype == MRMT3_F32 && out_dtype == MRMT3_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(b), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n / 4);
+  else if (in_dtype == MRMT3_BF16 && out_dtype == MRMT3_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(b), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n / 4);
+  else if (in_dtype == MRMT3_F32 && out_dtype == MRMT3_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(b), dim3(256), 0, s, (const float*)in, (float*)out, n / 4);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(b), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, n / 4);
+  MR_CHECK_LAUNCH("cast");
+  return MRMT3_OK;
+}
+
+template <typename TI, typename TO>
+__global__ void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      if constexpr (sizeof(TI) == 2) v = bf2f(in[(size_t)r * cols + c]);
+      else v = in[(size_t)r * cols + c];
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;  // out[c][r]
+    if (r < rows && c < cols) {
+      const float v = tile[tx][j];
+      if constexpr (sizeof(TO) == 2) out[(size_t)c * rows + r] = f2bf(v);
+      else out[(size_t)c * rows + r] = v;
+    }
+  }
+}
+
+extern "C" int mrmt3_transpose(const void* in, int in_dtype, void* out, int out_dtype, int rows, int cols,
+                               void* stream) {
+  MR_CHECK_ARG(in && out && rows > 0 && cols > 0, "transpose: bad args");
+  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == MRMT3_F32 && out_dtype == MRMT3_BF16)
+    hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, block, 0, s, (const float*)in, (bf16_t*)out, rows, cols);
+  else if (in_dtype == MRMT3_F32 && out_dtype == MRMT3_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, s, (const float*)in, (float*)out, rows, cols);
+  else if (in_dtype == MRMT3_BF16 && out_dtype == MRMT3_BF16)
+    hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)in, (bf16_t*)out, rows, cols);
+  else
+    hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)in, (float*)out, rows, cols);
+  MR_CHECK_LAUNCH("transpose");
+  return MRMT3_OK;
+}

@@ -1,0 +1,303 @@
+"""ctypes binding of libmrmt3_hip.so (include/mrmt3_hip.h).
+
+The product path has NO CPU fallback: `load()` raises if the shared library is missing, and every
+wrapper raises RuntimeError when the C ABI returns non-zero.  Tensors are passed as raw device
+pointers; shapes/strides are explicit.  The stream is torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import torch
+
+F32, BF16 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrmt3_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "mrmt3_hip.h")
+CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
+_lib = None
+
+vp, ci, cf, cu64, cu32, csz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
+
+_SIGS = {
+    "mrmt3_version": (ci, []),
+    "mrmt3_last_error": (C.c_char_p, []),
+    "mrmt3_logmel_fwd": (ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp]),
+    "mrmt3_gemm_nt": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "mrmt3_gemm_tn_workspace_bytes": (csz, [ci, ci, ci]),
+    "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
+    "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
+    "mrmt3_add_rmsnorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
+    "mrmt3_attn_fwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
+                            ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_embed_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_addpos_fwd": (ci, [vp, ci, vp, vp, ci, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_dropmask_cast": (ci, [vp, vp, csz, cf, cu64, cu32, vp]),
+    "mrmt3_ce_count": (ci, [vp, ci, ci, ci, ci, vp, vp]),
+    "mrmt3_ce_fwd_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]),
+    "mrmt3_adamw_step": (ci, [vp, vp, vp, vp, csz, vp, vp, cf, cf, cf, cf, cf, vp, vp]),
+    "mrmt3_transpose": (ci, [vp, ci, vp, ci, ci, ci, vp]),
+    "mrmt3_cast": (ci, [vp, ci, vp, ci, csz, vp]),
+    "mrmt3_decoder_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci, ci, ci, cf]),
+    "mrmt3_decoder_destroy": (None, [vp]),
+    "mrmt3_decoder_begin": (ci, [vp, vp, vp, vp, ci, ci, vp, ci, ci, ci, ci, vp]),
+    "mrmt3_decoder_run": (ci, [vp, ci, vp]),
+    "mrmt3_decoder_poll": (ci, [vp, vp, vp]),
+}
+
+
+def header_symbols(path: str = HEADER_PATH):
+    """Names of every function the C header declares."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrmt3_[a-z0-9_]+)\s*\(", txt)))
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libmrmt3_hip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC_DIR, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libmrmt3_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X kernels are the only implementation of this path "
+            "(no CPU fallback). Run `python __graft_entry__.py` / `make -C mr-mt3_amd/csrc` first.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {load().mrmt3_last_error().decode()}")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mrmt3 kernels need device tensors (no CPU fallback)")
+
+
+# ---- thin wrappers (shape checks live in the C library) -----------------------------------------
+
+def logmel(audio, tables, valid_frames=None, normalize=True, out_bf16=False):
+    _dev(audio)
+    B, n = audio.shape
+    hop, n_mels = tables["hop"], tables["n_mels"]
+    frames = -(-n // hop)
+    out = torch.empty(B, frames, n_mels, device=audio.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _check(load().mrmt3_logmel_fwd(_p(audio), B, n, hop, _p(tables["window"]), _p(tables["twiddle"]),
+                                   _p(tables["fb_start"]), _p(tables["fb_cnt"]), _p(tables["fb_w"]), n_mels,
+                                   tables["max_taps"], _p(valid_frames), int(normalize), int(out_bf16), _p(out),
+                                   _stream()), "logmel_fwd")
+    return out
+
+
+def gemm_nt(a, b, out=None, out_dtype=None, accumulate=False):
+    """out[M,N] (+)= a[M,K] @ b[N,K]^T ; a/b are 2-D, last dim contiguous (row stride may exceed K)."""
+    _dev(a, b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
+    assert out.stride(1) == 1
+    _check(load().mrmt3_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _dt(a),
+                                _dt(out), int(accumulate), _stream()), "gemm_nt")
+    return out
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index if hasattr(device, "index") else 0)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def gemm_tn(a, b, out, accumulate=False):
+    """out[N1,N2] (+)= a[M,N1]^T @ b[M,N2]  (bf16 in, f32 out)."""
+    _dev(a, b, out)
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    lib = load()
+    nbytes = lib.mrmt3_gemm_tn_workspace_bytes(M, N1, N2)
+    ws = workspace(nbytes, a.device)
+    _check(lib.mrmt3_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N1, N2,
+                             int(accumulate), _p(ws), ws.numel(), _stream()), "gemm_tn")
+    return out
+
+
+def add_rmsnorm_fwd(x0, y, w, eps, xn_dtype, write_x1=True, p=0.0, seed=0, stream_y=0, stream_out=0,
+                    out_drop=False, x1=None):
+    _dev(x0, y, w)
+    rows, cols = x0.shape
+    if x1 is None and write_x1:
+        x1 = torch.empty_like(x0)
+    xn = torch.empty(rows, cols, device=x0.device, dtype=xn_dtype)
+    rstd = torch.empty(rows, device=x0.device, dtype=torch.float32)
+    _check(load().mrmt3_add_rmsnorm_fwd(_p(x0), _p(y), _dt(y) if y is not None else F32, _p(w), eps, _p(x1), _p(xn),
+                                        _dt(xn), _p(rstd), rows, cols, p, seed, stream_y, stream_out, int(out_drop),
+                                        _stream()), "add_rmsnorm_fwd")
+    return (x1 if x1 is not None else x0), xn, rstd
+
+
+def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, stream_y=0, stream_out=0,
+                    out_drop=False, dx1=None):
+    _dev(dxn, x1, rstd, w)
+    rows, cols = x1.shape
+    if dx1 is None:
+        dx1 = torch.empty_like(x1)
+    dy = torch.empty(rows, cols, device=x1.device, dtype=torch.bfloat16) if want_dy else None
+    _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _p(dres), _p(x1), _p(rstd), _p(w), _p(dx1), _p(dy), _p(dw), rows,
+                                        cols, p, seed, stream_y, stream_out, int(out_drop), _stream()),
+           "add_rmsnorm_bwd")
+    return dx1, dy
+
+
+def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse=True):
+    """q: [B*Lq, ldq-view], k/v: [B*Lk, ld-view] 2-D views whose column 0 is head 0 / dim 0."""
+    _dev(q, k, v)
+    o = torch.empty(B * Lq, H * 64, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
+    _check(load().mrmt3_attn_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                 _p(lse), B, H, Lq, Lk, int(causal), _dt(q), p, seed, stream_id, _stream()),
+           "attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0):
+    _dev(q, k, v, o, d_o, lse, dq, dk, dv)
+    delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    _check(load().mrmt3_attn_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                 _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk),
+                                 dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, int(causal), p, seed, stream_id,
+                                 _stream()), "attn_bwd")
+    return dq, dk, dv
+
+
+def geglu_fwd(h, p=0.0, seed=0, stream_id=0):
+    _dev(h)
+    rows, two = h.shape
+    g = torch.empty(rows, two // 2, device=h.device, dtype=h.dtype)
+    _check(load().mrmt3_geglu_fwd(_p(h), _p(g), rows, two // 2, _dt(h), p, seed, stream_id, _stream()), "geglu_fwd")
+    return g
+
+
+def geglu_bwd(h, dg, p=0.0, seed=0, stream_id=0):
+    _dev(h, dg)
+    rows, two = h.shape
+    dh = torch.empty_like(h)
+    _check(load().mrmt3_geglu_bwd(_p(h), _p(dg), _p(dh), rows, two // 2, p, seed, stream_id, _stream()), "geglu_bwd")
+    return dh
+
+
+def embed_fwd(ids, table, pos, seq_len, shift, start_id=0, pad_id=0, pos_offset=0, p=0.0, seed=0, stream_id=0):
+    _dev(ids, table, pos)
+    rows = ids.numel()
+    V, d = table.shape
+    x = torch.empty(rows, d, device=table.device, dtype=torch.float32)
+    _check(load().mrmt3_embed_fwd(_p(ids), _p(table), _p(pos), _p(x), rows, seq_len, d, V, int(shift), start_id,
+                                  pad_id, pos_offset, p, seed, stream_id, _stream()), "embed_fwd")
+    return x
+
+
+def embed_bwd(ids, dx, dtable, seq_len, shift, start_id=0, pad_id=0, p=0.0, seed=0, stream_id=0):
+    _dev(ids, dx, dtable)
+    rows = ids.numel()
+    V, d = dtable.shape
+    _check(load().mrmt3_embed_bwd(_p(ids), _p(dx), _p(dtable), rows, seq_len, d, V, int(shift), start_id, pad_id, p,
+                                  seed, stream_id, _stream()), "embed_bwd")
+
+
+def addpos_fwd(src, pos, seq_len, pos_offset=0, p=0.0, seed=0, stream_id=0):
+    _dev(src, pos)
+    rows, d = src.shape
+    x = torch.empty(rows, d, device=src.device, dtype=torch.float32)
+    _check(load().mrmt3_addpos_fwd(_p(src), _dt(src), _p(pos), _p(x), rows, seq_len, d, pos_offset, p, seed,
+                                   stream_id, _stream()), "addpos_fwd")
+    return x
+
+
+def dropmask_cast(dx, p=0.0, seed=0, stream_id=0):
+    _dev(dx)
+    out = torch.empty(dx.shape, device=dx.device, dtype=torch.bfloat16)
+    _check(load().mrmt3_dropmask_cast(_p(dx), _p(out), dx.numel(), p, seed, stream_id, _stream()), "dropmask_cast")
+    return out
+
+
+def cross_entropy(logits, targets, want_grad=True, grad_dtype=torch.bfloat16, weighted=False, inst_lo=1135,
+                  inst_hi=1262, grad_scale=1.0):
+    """Returns (loss_dev[1] f32 tensor, dlogits or None).  No host sync."""
+    _dev(logits, targets)
+    rows, V = logits.shape
+    acc = torch.zeros(2, device=logits.device, dtype=torch.float32)  # [loss, denom]
+    lib = load()
+    _check(lib.mrmt3_ce_count(_p(targets), rows, int(weighted), inst_lo, inst_hi, C.c_void_p(acc.data_ptr() + 4),
+                              _stream()), "ce_count")
+    dl = torch.empty(rows, V, device=logits.device, dtype=grad_dtype) if want_grad else None
+    _check(lib.mrmt3_ce_fwd_bwd(_p(logits), _p(targets), C.c_void_p(acc.data_ptr() + 4), _p(acc), _p(dl),
+                                _dt(dl) if dl is not None else F32, rows, V, int(weighted), inst_lo, inst_hi,
+                                grad_scale, _stream()), "ce_fwd_bwd")
+    return acc[0:1], dl
+
+
+def adamw_step(p, g, m, v, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0,
+               shadow=None):
+    _dev(p, g, m, v, lr_dev, step_dev)
+    _check(load().mrmt3_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), _p(step_dev), beta1, beta2,
+                                   eps, weight_decay, grad_scale, _p(shadow), _stream()), "adamw_step")
+
+
+def transpose(src, out):
+    _dev(src, out)
+    rows, cols = src.shape
+    _check(load().mrmt3_transpose(_p(src), _dt(src), _p(out), _dt(out), rows, cols, _stream()), "transpose")
+    return out
+
+
+def cast(src, out):
+    _dev(src, out)
+    _check(load().mrmt3_cast(_p(src), _dt(src), _p(out), _dt(out), src.numel(), _stream()), "cast")
+    return out

@@ -1,0 +1,78 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mrmt3_hip.h declares
+(no compute calls without a GPU), the frontend oracle's known-answer anchors, and the inference
+harness restatement (hand-derived answers from inference.py:64-136,206-215)."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mrmt3 import lib
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(lib.LIB_PATH), "run __graft_entry__.build() first"
+    names = lib.header_symbols()
+    assert len(names) >= 25
+    so = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+    assert set(names) == set(lib._SIGS), set(names) ^ set(lib._SIGS)
+    assert lib.load().mrmt3_version() >= 100
+
+
+def test_product_path_refuses_cpu_tensors():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.gemm_nt(torch.zeros(128, 64), torch.zeros(128, 64))
+
+
+def test_filterbank_anchors():
+    """SURVEY §8c anchors for the (unpinned) torchaudio filterbank restatement."""
+    from oracle import logmel_ref
+    from contrib import spectrograms as sp
+    fb = logmel_ref.melscale_fbanks()
+    assert fb.shape == (1025, 512)
+    assert int((fb > 0).sum()) == 1934
+    zero_filters = np.nonzero((fb.numpy() > 0).sum(0) == 0)[0]
+    assert len(zero_filters) == 2 and zero_filters.max() <= 10
+    nzbins = np.nonzero((fb.numpy() > 0).sum(1))[0]
+    assert nzbins.min() == 3 and nzbins.max() == 972
+    # the product builds the same matrix (same fp32 torch ops)
+    assert torch.equal(sp.mel_filterbank(1025, 20.0, 7600.0, 512, 16000), fb)
+
+
+def test_frontend_oracle_known_answers():
+    from oracle import logmel_ref
+    x = np.random.RandomState(0).uniform(-1, 1, 32768).astype(np.float32)
+    assert logmel_ref.pad_end(torch.from_numpy(x)).shape[-1] == 32768 + 1920
+    mel = logmel_ref.compute_spectrogram(x)
+    assert mel.shape == (256, 512) and mel.dtype == np.float32
+    fb = logmel_ref.melscale_fbanks().numpy()
+    dead = np.nonzero((fb > 0).sum(0) == 0)[0]
+    assert np.allclose(mel[:, dead], math.log(1e-5))
+    assert np.allclose(logmel_ref.normalize_mel(mel)[:, dead], 0.02865, atol=1e-5)
+    # pure tone at bin 128 (1 kHz): the loudest mel filter is the one whose triangle covers it
+    t = np.arange(32768) / 16000.0
+    tone = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    m = logmel_ref.compute_spectrogram(tone)[5]
+    assert fb[128, m.argmax()] > 0.5
+
+
+def test_inference_harness_known_answers():
+    from oracle import logmel_ref
+    import inference as prod
+    for n, nfr, pads in ((40000, 313, [256, 57]), (32768, 257, [256, 1])):
+        audio = np.random.RandomState(n).uniform(-1, 1, n).astype(np.float32)
+        fr, times = logmel_ref.audio_to_frames(audio)
+        assert fr.shape == (nfr, 128)
+        segs, ft, paddings = logmel_ref.split_into_segments(fr, times)
+        assert segs.shape == (2, 256, 128) and paddings == pads
+        # product host logic agrees with the restatement
+        pfr, ptimes = prod.audio_to_frames(audio)
+        psegs, pft, ppads = prod.split_into_segments(pfr, ptimes)
+        assert np.array_equal(psegs, segs) and np.array_equal(pft, ft) and ppads == pads
+    ids = np.array([[0, 7, 9, 1, 5]])
+    assert logmel_ref.postprocess_batch(ids).tolist() == [[4, 6, -1, -1]]
+    assert prod.postprocess_batch(torch.from_numpy(ids)).tolist() == [[4, 6, -1, -1]]

@@ -1,0 +1,394 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against a plain fp32 PyTorch
+restatement of the same op (or the oracle) on identical seeded inputs.  Tolerances are stated per
+test; integer / index work is bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from mrmt3 import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+
+
+# ---- K1 log-mel -------------------------------------------------------------------------------------
+
+def test_logmel_matches_oracle(dev):
+    from contrib import spectrograms as sp
+    from mrmt3.synthetic import synth_audio
+    from oracle import logmel_ref
+    audio = synth_audio(3)
+    ref = logmel_ref.logmel_segments(audio)                      # [3,256,512] normalised
+    got = sp.logmel_segments(torch.from_numpy(audio).to(dev)).cpu().numpy()
+    assert got.shape == (3, 256, 512)
+    # tolerance: 1e-4 absolute on the [0,1]-normalised log-mel
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
+    # un-normalised API + the reference's numpy signature
+    one = sp.compute_spectrogram(audio[0], sp.SpectrogramConfig())
+    np.testing.assert_allclose(one, logmel_ref.compute_spectrogram(audio[0]), atol=2e-3, rtol=0)
+
+
+def test_logmel_edge_cases(dev):
+    from contrib import spectrograms as sp
+    from oracle import logmel_ref
+    rs = np.random.RandomState(1)
+    # ragged length (not a hop multiple), silence, and a pure tone
+    x = rs.uniform(-1, 1, size=(1, 40000)).astype(np.float32)
+    got = sp.logmel_segments(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = logmel_ref.logmel_segments(x)
+    assert got.shape == ref.shape == (1, 313, 512)
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0)
+    z = np.zeros((1, 32768), np.float32)
+    got = sp.logmel_segments(torch.from_numpy(z).to(dev)).cpu().numpy()
+    assert np.allclose(got, (math.log(1e-5) + 12) / 17, atol=1e-6)      # safe_log floor everywhere
+    t = np.arange(32768) / 16000.0
+    tone = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)[None]
+    got = sp.logmel_segments(torch.from_numpy(tone).to(dev), normalize=False).cpu().numpy()
+    ref = np.stack([logmel_ref.compute_spectrogram(tone[0])])
+    assert got[0, 10].argmax() == ref[0, 10].argmax()
+    big = ref > ref.max() - 8.0                                         # fp32 FFT noise floor below that
+    np.testing.assert_allclose(got[big], ref[big], atol=2e-3, rtol=0)
+    # valid_frames zeroing (inference.py:125-126) and bf16 output
+    vf = torch.tensor([100], dtype=torch.int32, device=dev)
+    g = sp.logmel_segments(torch.from_numpy(x[:, :32768]).to(dev), valid_frames=vf).cpu().numpy()
+    assert (g[0, 100:] == 0).all() and (g[0, :100] != 0).any()
+    gb = sp.logmel_segments(torch.from_numpy(x[:, :32768]).to(dev), out_bf16=True).float().cpu().numpy()
+    np.testing.assert_allclose(gb, logmel_ref.logmel_segments(x[:, :32768]), atol=4e-3, rtol=0)
+
+
+# ---- GEMMs ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 1152, 512), (4096, 512, 384), (130, 2048, 512),
+                                   (2048, 512, 1024), (64, 1536, 512)])
+def test_gemm_nt_bf16(dev, M, N, K):
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    b = torch.randn(N, K, generator=g).to(dev).bfloat16()
+    ref = a.float() @ b.float().t()
+    out32 = lib.gemm_nt(a, b, out_dtype=torch.float32)
+    assert _rel(out32, ref) < 1e-5                       # fp32 accumulation of exact bf16 products
+    out16 = lib.gemm_nt(a, b, out_dtype=torch.bfloat16)
+    assert _rel(out16, ref) < 4e-3                       # one bf16 rounding of the result
+    acc = torch.ones(M, N, device=dev)
+    lib.gemm_nt(a, b, out=acc, accumulate=True)
+    assert _rel(acc, ref + 1.0) < 1e-5
+
+
+def test_gemm_nt_strided_and_asymmetric(dev):
+    from mrmt3 import lib
+    # A = I (padded) with an asymmetric B catches a transposed C write
+    K = 128
+    a = torch.zeros(128, K, device=dev)
+    a[:, :128] = torch.eye(128, device=dev)
+    b = torch.arange(256 * K, device=dev, dtype=torch.float32).reshape(256, K) % 251
+    out = lib.gemm_nt(a.bfloat16(), b.bfloat16(), out_dtype=torch.float32)
+    assert torch.equal(out, b[:, :128].t().contiguous())
+    # row-strided views (q slice of a fused qkv buffer)
+    big = torch.randn(300, 1152, device=dev).bfloat16()
+    w = torch.randn(512, 384, device=dev).bfloat16()
+    out = lib.gemm_nt(big[:, 384:768], w, out_dtype=torch.float32)
+    assert _rel(out, big[:, 384:768].float() @ w.float().t()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (777, 1152, 512), (300, 512, 1024)])
+def test_gemm_nt_f32(dev, M, N, K):
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = torch.randn(M, K, generator=g).to(dev)
+    b = torch.randn(N, K, generator=g).to(dev)
+    ref = (a.double() @ b.double().t())
+    out = lib.gemm_nt(a, b)
+    assert _rel(out.double(), ref) < 2e-6                # exact-f32 MFMA chain
+
+
+@pytest.mark.parametrize("M,N1,N2", [(512, 128, 128), (4096, 1152, 512), (1000, 512, 384), (8192, 2048, 512),
+                                     (640, 1536, 512)])
+def test_gemm_tn(dev, M, N1, N2):
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(M)
+    a = torch.randn(M, N1, generator=g).to(dev).bfloat16()
+    b = torch.randn(M, N2, generator=g).to(dev).bfloat16()
+    ref = a.float().t() @ b.float()
+    out = torch.full((N1, N2), 7.0, device=dev)
+    lib.gemm_tn(a, b, out)
+    assert _rel(out, ref) < 1e-5
+    out2 = torch.ones(N1, N2, device=dev)
+    lib.gemm_tn(a, b, out2, accumulate=True)
+    assert _rel(out2, ref + 1.0) < 1e-5
+    out3 = torch.empty(N1, N2, device=dev)
+    lib.gemm_tn(a, b, out3)
+    assert torch.equal(out, out3)                        # fixed-order slab reduction: bitwise reproducible
+
+
+# ---- RMS norm ----------------------------------------------------------------------------------------
+
+def _rms_ref(x, w, eps=1e-6):
+    return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+def test_add_rmsnorm_fwd_bwd(dev, ydt):
+    from mrmt3 import lib
+    rows, cols = 1000, 512
+    x0 = torch.randn(rows, cols, device=dev)
+    y = torch.randn(rows, cols, device=dev).to(ydt)
+    w = (1 + 0.1 * torch.randn(cols, device=dev))
+    x1, xn, rstd = lib.add_rmsnorm_fwd(x0, y, w, 1e-6, torch.float32)
+    x1r = (x0 + y.float()).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    xnr = _rms_ref(x1r, wr)
+    assert torch.allclose(x1, x1r, atol=1e-6) and torch.allclose(xn, xnr, atol=2e-6, rtol=1e-5)
+    _, xnb, _ = lib.add_rmsnorm_fwd(x0, y, w, 1e-6, torch.bfloat16)
+    assert _rel(xnb, xnr) < 4e-3
+    _, xn0, _ = lib.add_rmsnorm_fwd(x0, None, w, 1e-6, torch.float32, write_x1=False)
+    assert torch.allclose(xn0, _rms_ref(x0, w), atol=2e-6, rtol=1e-5)
+    # backward
+    dxn = torch.randn(rows, cols, device=dev)
+    dres = torch.randn(rows, cols, device=dev)
+    (xnr * dxn).sum().backward()
+    dw = torch.zeros(cols, device=dev)
+    dx1, dy = lib.add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw)
+    assert torch.allclose(dx1, x1r.grad + dres, atol=1e-5, rtol=1e-4)
+    assert _rel(dy, x1r.grad + dres) < 4e-3
+    assert _rel(dw, wr.grad) < 1e-5
+
+
+def test_dropout_sites_consistent(dev):
+    """Masks are a pure function of (seed, stream, index): forward and backward agree, keep rate is
+    1-p, kept values are scaled by 1/(1-p)."""
+    from mrmt3 import lib
+    rows, cols, p = 2048, 512, 0.1
+    x0 = torch.zeros(rows, cols, device=dev)
+    y = torch.ones(rows, cols, device=dev)
+    w = torch.ones(cols, device=dev)
+    x1, _, rstd = lib.add_rmsnorm_fwd(x0, y, w, 1e-6, torch.float32, p=p, seed=1234, stream_y=5)
+    keep = (x1 != 0)
+    assert abs(keep.float().mean().item() - 0.9) < 2e-3
+    assert torch.allclose(x1[keep], torch.full_like(x1[keep], 1 / 0.9))
+    m2 = lib.dropmask_cast(torch.ones(rows, cols, device=dev), p=p, seed=1234, stream_id=5).float()
+    assert torch.equal(m2 != 0, keep)
+    m3 = lib.dropmask_cast(torch.ones(rows, cols, device=dev), p=p, seed=1234, stream_id=6).float()
+    assert not torch.equal(m3 != 0, keep)
+
+
+# ---- attention ---------------------------------------------------------------------------------------
+
+def _attn_ref(q, k, v, B, H, Lq, Lk, causal):
+    qh = q.float().view(B, Lq, H, 64).transpose(1, 2)
+    kh = k.float().view(B, Lk, H, 64).transpose(1, 2)
+    vh = v.float().view(B, Lk, H, 64).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3)
+    if causal:
+        i = torch.arange(Lq, device=q.device)[:, None]
+        j = torch.arange(Lk, device=q.device)[None, :]
+        s = s.masked_fill(j > i, float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B * Lq, H * 64), torch.logsumexp(s, -1)
+
+
+ATTN_SHAPES = [(2, 6, 256, 256, False), (2, 6, 1024, 1024, True), (1, 6, 1024, 320, False),
+               (2, 3, 200, 72, False), (1, 2, 300, 300, True), (1, 6, 64, 1024, False), (1, 1, 1088, 1088, True)]
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", ATTN_SHAPES)
+def test_attn_fwd_bf16(dev, B, H, Lq, Lk, causal):
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(Lq * 7 + Lk)
+    q = (torch.randn(B * Lq, H * 64, generator=g) * 0.35).to(dev).bfloat16()
+    k = torch.randn(B * Lk, H * 64, generator=g).to(dev).bfloat16()
+    v = torch.randn(B * Lk, H * 64, generator=g).to(dev).bfloat16()
+    o, lse = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal)
+    oref, lref = _attn_ref(q, k, v, B, H, Lq, Lk, causal)
+    assert torch.allclose(lse, lref, atol=2e-3, rtol=1e-4)
+    assert _rel(o, oref) < 1e-2 and (o.float() - oref).abs().max() < 3e-2
+
+
+def test_attn_fwd_fused_qkv_layout(dev):
+    """q/k/v as column slices of one [rows, 1152] buffer (the fused-QKV GEMM output)."""
+    from mrmt3 import lib
+    B, H, L = 2, 6, 256
+    qkv = torch.randn(B * L, 1152, device=dev).bfloat16()
+    qkv[:, :384] *= 0.35
+    o, _ = lib.attn_fwd(qkv[:, 0:384], qkv[:, 384:768], qkv[:, 768:1152], B, H, L, L, False)
+    oref, _ = _attn_ref(qkv[:, 0:384].contiguous(), qkv[:, 384:768].contiguous(), qkv[:, 768:].contiguous(), B, H, L, L, False)
+    assert _rel(o, oref) < 1e-2
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", ATTN_SHAPES)
+def test_attn_bwd_bf16(dev, B, H, Lq, Lk, causal):
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(Lq * 3 + Lk)
+    q = (torch.randn(B * Lq, H * 64, generator=g) * 0.35).to(dev).bfloat16()
+    k = torch.randn(B * Lk, H * 64, generator=g).to(dev).bfloat16()
+    v = torch.randn(B * Lk, H * 64, generator=g).to(dev).bfloat16()
+    d_o = torch.randn(B * Lq, H * 64, generator=g).to(dev).bfloat16()
+    o, lse = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    oref, _ = _attn_ref(qr, kr, vr, B, H, Lq, Lk, causal)
+    (oref * d_o.float()).sum().backward()
+    # bf16 P/dS operands + bf16 outputs: ~1e-2 relative per tensor
+    assert _rel(dq, qr.grad) < 2e-2, _rel(dq, qr.grad)
+    assert _rel(dk, kr.grad) < 2e-2, _rel(dk, kr.grad)
+    assert _rel(dv, vr.grad) < 2e-2, _rel(dv, vr.grad)
+
+
+def test_attn_online_softmax_rescale_branch(dev):
+    """Force the running max to jump at a late key tile (one key spiked against one query)."""
+    from mrmt3 import lib
+    B, H, L = 1, 1, 512
+    q = (torch.randn(L, 64, device=dev) * 0.3).bfloat16()
+    k = torch.randn(L, 64, device=dev).bfloat16()
+    v = torch.randn(L, 64, device=dev).bfloat16()
+    k[450] = (q[17].float() * 40).bfloat16()
+    o, lse = lib.attn_fwd(q, k, v, B, H, L, L, False)
+    oref, lref = _attn_ref(q, k, v, B, H, L, L, False)
+    assert torch.allclose(lse, lref, atol=5e-3, rtol=1e-4) and _rel(o, oref) < 1e-2
+
+
+def test_attn_dropout_statistics_and_bwd_mask(dev):
+    from mrmt3 import lib
+    B, H, L = 1, 2, 256
+    q = torch.zeros(B * L, H * 64, device=dev).bfloat16()          # uniform attention
+    k = torch.zeros(B * L, H * 64, device=dev).bfloat16()
+    v = torch.ones(B * L, H * 64, device=dev).bfloat16()
+    o, lse = lib.attn_fwd(q, k, v, B, H, L, L, False, p=0.1, seed=99, stream_id=3)
+    # each output = (#kept / L) / 0.9 -> mean 1, small spread
+    assert abs(o.float().mean().item() - 1.0) < 5e-3 and 0.005 < o.float().std().item() < 0.05
+    # dV with dO = 1: dV[k] = sum_q Pd[q,k] -> mean 1 too, and must use the SAME mask as forward:
+    d_o = torch.ones_like(o)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, L, False, p=0.1, seed=99, stream_id=3)
+    assert abs(dv.float().mean().item() - 1.0) < 5e-3
+    # consistency: sum_k dV[k,d] == sum_q O[q,d] (both equal sum_{q,k} Pd[q,k]) per head
+    s_o = o.float().view(L, H, 64).sum(0)[:, 0]
+    s_dv = dv.float().view(L, H, 64).sum(0)[:, 0]
+    assert torch.allclose(s_o, s_dv, rtol=2e-3)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 6, 256, 256, False), (1, 6, 128, 128, True), (1, 6, 100, 320, False)])
+def test_attn_f32(dev, B, H, Lq, Lk, causal):
+    from mrmt3 import lib
+    q = torch.randn(B * Lq, H * 64, device=dev) * 0.35
+    k = torch.randn(B * Lk, H * 64, device=dev)
+    v = torch.randn(B * Lk, H * 64, device=dev)
+    o, lse = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal)
+    oref, lref = _attn_ref(q, k, v, B, H, Lq, Lk, causal)
+    assert torch.allclose(o, oref, atol=2e-5, rtol=1e-5) and torch.allclose(lse, lref, atol=1e-5)
+
+
+# ---- gated GELU, embedding, CE, AdamW ------------------------------------------------------------------
+
+def _gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+def test_geglu(dev):
+    from mrmt3 import lib
+    h = torch.randn(777, 2048, device=dev)
+    g = lib.geglu_fwd(h)
+    assert torch.allclose(g, _gelu_new(h[:, :1024]) * h[:, 1024:], atol=1e-6, rtol=1e-5)
+    hb = h.bfloat16()
+    gb = lib.geglu_fwd(hb)
+    hr = hb.float().requires_grad_(True)
+    gr = _gelu_new(hr[:, :1024]) * hr[:, 1024:]
+    assert _rel(gb, gr) < 4e-3
+    dg = torch.randn(777, 1024, device=dev).bfloat16()
+    (gr * dg.float()).sum().backward()
+    dh = lib.geglu_bwd(hb, dg)
+    assert _rel(dh, hr.grad) < 4e-3
+
+
+def test_embed_shift_right_and_scatter(dev):
+    from mrmt3 import lib
+    from mrmt3.synthetic import sinusoid_table, synth_labels
+    B, L, d, V = 3, 64, 512, 1536
+    table = torch.randn(V, d, device=dev)
+    pos = sinusoid_table(128, d).to(dev)
+    labels = torch.from_numpy(synth_labels(B, L, full=False, mean_len=20)).to(dev)
+    x = lib.embed_fwd(labels, table, pos, L, shift=True)
+    ids = torch.cat([torch.zeros(B, 1, dtype=torch.long, device=dev), labels[:, :-1]], 1)
+    ids = ids.masked_fill(ids == -100, 0)
+    ref = table[ids] + pos[None, :L]
+    assert torch.equal(x.view(B, L, d), ref)                    # gather + one fp32 add: bit-exact
+    dx = torch.randn(B * L, d, device=dev)
+    dt = torch.zeros(V, d, device=dev)
+    lib.embed_bwd(labels, dx, dt, L, shift=True)
+    dref = torch.zeros(V, d, device=dev).index_add_(0, ids.view(-1), dx)
+    assert torch.allclose(dt, dref, atol=1e-5)
+    x2 = lib.embed_fwd(ids, table, pos, L, shift=False, pos_offset=3)
+    assert torch.equal(x2.view(B, L, d), table[ids] + pos[None, 3:3 + L])
+    src = torch.randn(B * L, d, device=dev)
+    assert torch.equal(lib.addpos_fwd(src, pos, L).view(B, L, d), src.view(B, L, d) + pos[None, :L])
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_cross_entropy(dev, weighted):
+    from mrmt3 import lib
+    from mrmt3.synthetic import synth_labels
+    from oracle import t5_ref
+    rows, V = 2048, 1536
+    logits = torch.randn(rows, V, device=dev) * 2
+    tg = torch.from_numpy(synth_labels(2, 1024, full=False)).to(dev).view(-1)
+    if weighted:
+        tg = tg.masked_fill(tg == -100, 5)   # the reference's weighted loss cannot take -100 rows... keep some
+        tg[::7] = -100
+    loss, dl = lib.cross_entropy(logits, tg, grad_dtype=torch.float32, weighted=weighted)
+    lr = logits.double().cpu().requires_grad_(True)
+    ref = (t5_ref.weighted_ce_loss if weighted else t5_ref.ce_loss)(lr[None], tg.cpu()[None])
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    assert torch.allclose(dl.cpu().double(), lr.grad, atol=1e-8, rtol=1e-4)
+
+
+def test_adamw_matches_torch(dev):
+    from mrmt3 import lib
+    n = 4096 * 3
+    p0 = torch.randn(n, device=dev)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=2e-4)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lr = torch.tensor([2e-4], device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    shadow = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    for i in range(5):
+        g = torch.randn(n, device=dev)
+        ref_p.grad = g.clone()
+        opt.step()
+        lib.adamw_step(p, g, m, v, lr, step, shadow=shadow)
+    assert step.item() == 5
+    assert torch.allclose(p, ref_p.data, atol=1e-7, rtol=1e-6)
+    assert torch.equal(shadow, p.bfloat16())
+
+
+def test_transpose_cast(dev):
+    from mrmt3 import lib
+    w = torch.randn(384, 512, device=dev)
+    out = torch.empty(512, 384, device=dev, dtype=torch.bfloat16)
+    lib.transpose(w, out)
+    assert torch.equal(out, w.t().contiguous().bfloat16())
+    c = torch.empty(384 * 512, device=dev, dtype=torch.bfloat16)
+    lib.cast(w.view(-1), c)
+    assert torch.equal(c, w.view(-1).bfloat16())
+
+
+def test_errors_are_reported_not_fatal(dev):
+    from mrmt3 import lib
+    a = torch.randn(64, 40, device=dev).bfloat16()   # K*2 not a multiple of 128
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        lib.gemm_nt(a, a)
+    with pytest.raises(RuntimeError, match="device tensors"):
+        lib.gemm_nt(torch.zeros(128, 64).bfloat16(), torch.zeros(128, 64).bfloat16())
