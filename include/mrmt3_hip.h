@@ -117,7 +117,8 @@ int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, 
  * models/t5.py:539-540,596-601 and `_shift_right` (t5.py:148-150).
  * ids [rows] int64.  shift!=0 applies HF _shift_right inside the gather: position t of a
  * sequence of length seq_len uses ids[t-1] (start_id at t==0) and maps -100 -> pad_id.
- * x [rows][d] f32 = table[id] + pos[(row % seq_len) + pos_offset], then dropout. */
+ * x [rows][d] f32 = table[id] + pos[(row % seq_len) + pos_offset], then dropout.
+ * pos may be NULL (plain gather, used for the segment-memory ids). */
 int mrmt3_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* x, int rows,
                     int seq_len, int d, int vocab, int shift, int start_id, int pad_id,
                     int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
@@ -189,14 +190,17 @@ int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_model, int n_h
                          int vocab, int max_batch, int max_len, int max_enc_len, int w_dtype,
                          float eps);
 void mrmt3_decoder_destroy(mrmt3_decoder* dec);
-/* Start a batch: cross_k/cross_v [layers][B][Lenc][inner] (act dtype = w_dtype) are caller-owned
- * (computed with mrmt3_gemm_nt from the encoder output); resets positions, finished flags and
- * writes start_id as token 0.  tokens_out [B][max_len+1] int64 is caller-owned. */
-int mrmt3_decoder_begin(mrmt3_decoder* dec, const mrmt3_decoder_weights* w, const void* cross_k,
-                        const void* cross_v, int batch, int enc_len, int64_t* tokens_out,
-                        int start_id, int eos_id, int pad_id, int stop_at_eos_mode, void* stream);
+/* Start a batch: cross_kv [layers][B*enc_len][2*inner] (k | v columns, dtype = w_dtype) is
+ * caller-owned (computed with mrmt3_gemm_nt from the encoder output [+ segment memory]); resets the
+ * step counter and finished flags and writes start_id as token 0.  tokens_out [B][max_len+1] int64 is
+ * caller-owned.  A row that has emitted eos_id keeps emitting pad_id (models/t5.py:288). */
+int mrmt3_decoder_begin(mrmt3_decoder* dec, const mrmt3_decoder_weights* w, const void* cross_kv,
+                        int batch, int enc_len, int64_t* tokens_out, int start_id, int eos_id,
+                        int pad_id, void* stream);
 /* Run n_steps decode steps (graph replays; captured on first use).  No host synchronisation. */
 int mrmt3_decoder_run(mrmt3_decoder* dec, int n_steps, void* stream);
+/* 1 if the current configuration is being replayed from a captured hipGraph (0 = plain launches). */
+int mrmt3_decoder_graph_captured(const mrmt3_decoder* dec);
 /* state_out[0] = steps taken so far, [1] = 1 if every row has emitted EOS, [2] = step index at
  * which the last row finished (or -1).  Copies 3 int32 asynchronously to caller-owned PINNED host
  * memory; the caller synchronises the stream before reading. */

@@ -1,13 +1,418 @@
-// K12 placeholder — replaced by the KV-cached hipGraph decoder later in this round.
+// K12 — greedy autoregressive decode with a self-attention KV cache, one hipGraph replay per token.
+//
+// Stands for the decoder loop of models/t5.py:267-295 (batched, MT3Net) and
+// models/t5_segmem_v2_with_prev.py:273-291 (one segment at a time).  The reference re-runs the
+// whole decoder over the growing prefix for every token (no cache, O(L^2) GEMM work) and, in the
+// segment-memory model, synchronises with the host once per token (`.item()`, :284).  Here a step
+// is 66 small kernels captured once into a hipGraph:
+//   per layer  norm+QKV gemv (K/V appended to the cache) -> self-attention over the cache ->
+//              O gemv + residual -> norm+Q gemv -> cross-attention over the projected encoder
+//              states -> O gemv + residual -> norm + wi gemv + gated-GELU -> wo gemv + residual
+//   then       final norm + lm_head gemv -> argmax / EOS bookkeeping / next-token embedding.
+// The step index and the finished flags live in device memory, so replays need no host
+// interaction; the host polls an 12-byte status block only when it wants to stop early.
+// Decode is latency/cache-bandwidth bound: every kernel reads its weight rows once with 16-byte
+// loads straight to registers (no LDS round trip for data used once), B<=8 sequences share each
+// weight read, and the 45.6 MB (bf16) of per-step weights stay resident in the 256 MB Infinity Cache.
 #include "common.h"
-struct mrmt3_decoder { int dummy; };
-extern "C" int mrmt3_decoder_create(mrmt3_decoder** out, int, int, int, int, int, int, int, int, int, float) {
-  if (out) *out = nullptr;
-  mrmt3_set_error("decoder: not built yet");
-  return MRMT3_ERR_UNSUPPORTED;
+
+#define DMODEL 512
+#define DEC_MAXB 8
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-extern "C" void mrmt3_decoder_destroy(mrmt3_decoder*) {}
-extern "C" int mrmt3_decoder_begin(mrmt3_decoder*, const mrmt3_decoder_weights*, const void*, const void*, int, int,
-                                   int64_t*, int, int, int, int, void*) { return MRMT3_ERR_UNSUPPORTED; }
-extern "C" int mrmt3_decoder_run(mrmt3_decoder*, int, void*) { return MRMT3_ERR_UNSUPPORTED; }
-extern "C" int mrmt3_decoder_poll(mrmt3_decoder*, int32_t*, void*) { return MRMT3_ERR_UNSUPPORTED; }
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
+  u32x4 t = *(const u32x4*)p;
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+  v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xFFFF0000u);
+  v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xFFFF0000u);
+}
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+__device__ __forceinline__ float gelu_new_d(float x) {
+  const float c = 0.7978845608028654f;
+  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * (x * x * x))));
+}
+
+// state block: [0] step t, [1] all finished, [2] step at which the last row finished (-1), [4+b] finished[b]
+#define ST_T 0
+#define ST_ALL 1
+#define ST_FIN 2
+#define ST_FLAGS 4
+
+// ---- RMS norm of x[b] into LDS (every workgroup recomputes it: 512 floats per row) -----------------
+__device__ __forceinline__ void norm_to_lds(const float* __restrict__ x, const float* __restrict__ lnw, float eps,
+                                            int B, float* xn /*[B][512]*/, float* red /*[4]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = 0; b < B; ++b) {
+    const float a0 = x[b * DMODEL + tid], a1 = x[b * DMODEL + 256 + tid];
+    float ss = wave_sum(a0 * a0 + a1 * a1);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    ss = (red[0] + red[1]) + (red[2] + red[3]);
+    const float rstd = rsqrtf(ss / (float)DMODEL + eps);
+    xn[b * DMODEL + tid] = lnw[tid] * (a0 * rstd);
+    xn[b * DMODEL + 256 + tid] = lnw[256 + tid] * (a1 * rstd);
+    __syncthreads();
+  }
+}
+
+// MODE 0: out[b][n] (f32, ld = N)      — cross-attention q, lm_head logits
+// MODE 1: fused q|k|v: n < inner -> q scratch; else K / V cache row t of this layer
+// MODE 2: gated GELU: rows n and n+N of W ([2N][512]) -> out[b][n] = gelu_new(h0) * h1
+template <typename TW, int MODE>
+__global__ __launch_bounds__(256) void dec_norm_gemv(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                     const TW* __restrict__ W, int N, int B, float eps,
+                                                     float* __restrict__ out, TW* __restrict__ kc, TW* __restrict__ vc,
+                                                     int inner, size_t cache_bstride, const int* __restrict__ state) {
+  __shared__ float xn[DEC_MAXB * DMODEL];
+  __shared__ float red[4];
+  norm_to_lds(x, lnw, eps, B, xn, red);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = (MODE == 1) ? state[ST_T] : 0;
+  for (int n = (blockIdx.x * 4 + wave) * 2; n < (blockIdx.x * 4 + wave) * 2 + 2 && n < N; ++n) {
+    float w0[8], w1[8];
+    load8<TW>(W + (size_t)n * DMODEL + lane * 8, w0);
+    if (MODE == 2) load8<TW>(W + (size_t)(n + N) * DMODEL + lane * 8, w1);
+    for (int b = 0; b < B; ++b) {
+      const float* xb = xn + b * DMODEL + lane * 8;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s0 = fmaf(w0[e], xb[e], s0);
+        if (MODE == 2) s1 = fmaf(w1[e], xb[e], s1);
+      }
+      s0 = wave_sum(s0);
+      if (MODE == 2) s1 = wave_sum(s1);
+      if (lane == 0) {
+        if (MODE == 0) out[(size_t)b * N + n] = s0;
+        else if (MODE == 2) out[(size_t)b * N + n] = gelu_new_d(s0) * s1;
+        else {
+          if (n < inner) out[(size_t)b * inner + n] = s0;
+          else if (n < 2 * inner) stf<TW>(kc + b * cache_bstride + (size_t)t * inner + (n - inner), s0);
+          else stf<TW>(vc + b * cache_bstride + (size_t)t * inner + (n - 2 * inner), s0);
+        }
+      }
+    }
+  }
+}
+
+// x[b][n] += sum_k a[b][k] * W[n][k]   (O projections and FFN wo, residual add fused)
+template <typename TW>
+__global__ __launch_bounds__(256) void dec_gemv_res(const float* __restrict__ a, const TW* __restrict__ W,
+                                                    float* __restrict__ x, int N, int K, int B) {
+  extern __shared__ __attribute__((aligned(16))) float as[];  // [B][K]
+  for (int i = threadIdx.x; i < B * K; i += 256) as[i] = a[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = (blockIdx.x * 4 + wave) * 2; n < (blockIdx.x * 4 + wave) * 2 + 2 && n < N; ++n) {
+    float acc[DEC_MAXB];
+#pragma unroll
+    for (int b = 0; b < DEC_MAXB; ++b) acc[b] = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+      float w[8];
+      load8<TW>(W + (size_t)n * K + k0, w);
+#pragma unroll
+      for (int b = 0; b < DEC_MAXB; ++b) {
+        if (b < B) {
+          const float* ab = as + b * K + k0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[b] = fmaf(w[e], ab[e], acc[b]);
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < DEC_MAXB; ++b) {
+      if (b < B) {
+        const float s = wave_sum(acc[b]);
+        if (lane == 0) x[(size_t)b * N + n] += s;
+      }
+    }
+  }
+}
+
+// one (head, batch) per workgroup: softmax(q.K^T) V over `len` cached rows (len = t+1 or fixed)
+template <typename TC>
+__global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, const TC* __restrict__ kb,
+                                                const TC* __restrict__ vb, int ld, size_t bstride, int fixed_len,
+                                                const int* __restrict__ state, float* __restrict__ o, int inner) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[len] | q[64] | red[8] | part[256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int len = fixed_len > 0 ? fixed_len : state[ST_T] + 1;
+  float* sc = sm;
+  float* qs = sm + ((len + 3) & ~3);
+  float* red = qs + 64;
+  float* part = red + 8;
+  if (tid < 64) qs[tid] = q[(size_t)b * inner + h * 64 + tid];
+  __syncthreads();
+  const TC* kp = kb + b * bstride + h * 64;
+  const TC* vp = vb + b * bstride + h * 64;
+  float mx = -INFINITY;
+  for (int key = tid; key < len; key += 256) {
+    const TC* kr = kp + (size_t)key * ld;
+    float s = 0.f;
+#pragma unroll
+    for (int d0 = 0; d0 < 64; d0 += 8) {
+      float kv[8];
+      load8<TC>(kr + d0, kv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(qs[d0 + e], kv[e], s);
+    }
+    sc[key] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int key = tid; key < len; key += 256) {
+    const float p = expf(sc[key] - mx);
+    sc[key] = p;
+    se += p;
+  }
+  se = wave_sum(se);
+  if (lane == 0) red[4 + wave] = se;
+  __syncthreads();
+  se = (red[4] + red[5]) + (red[6] + red[7]);
+  float acc = 0.f;
+  for (int key = wave; key < len; key += 4) acc = fmaf(sc[key], ldf<TC>(vp + (size_t)key * ld + lane), acc);
+  part[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (tid < 64) o[(size_t)b * inner + h * 64 + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) / se;
+}
+
+// argmax + EOS bookkeeping (models/t5.py:286-295) + embedding of the next token; single workgroup
+__global__ __launch_bounds__(256) void dec_argmax(const float* __restrict__ logits, int V, int B, int64_t* __restrict__ tokens,
+                                                  int tok_ld, const float* __restrict__ embed, const float* __restrict__ pos,
+                                                  float* __restrict__ x, int* __restrict__ state, int eos, int pad) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  __shared__ int nxt_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = state[ST_T];
+  int all_done = 1;
+  for (int b = 0; b < B; ++b) {
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+      const float v = logits[(size_t)b * V + c];
+      if (v > best) { best = v; idx = c; }   // ascending c per thread: first maximum wins
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(idx, off, 64);
+      if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+      const int was_done = state[ST_FLAGS + b];
+      int nxt = was_done ? pad : idx;
+      if (!was_done && nxt == eos) state[ST_FLAGS + b] = 1;
+      tokens[(size_t)b * tok_ld + t + 1] = nxt;
+      nxt_s = nxt;
+    }
+    __syncthreads();
+    const int nxt = nxt_s;
+    all_done &= state[ST_FLAGS + b];
+    const float* er = embed + (size_t)nxt * DMODEL;
+    const float* pr = pos + (size_t)(t + 1) * DMODEL;
+    x[b * DMODEL + tid] = er[tid] + pr[tid];
+    x[b * DMODEL + 256 + tid] = er[256 + tid] + pr[256 + tid];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (all_done && !state[ST_ALL]) { state[ST_ALL] = 1; state[ST_FIN] = t; }
+    state[ST_T] = t + 1;
+  }
+}
+
+__global__ void dec_begin_kernel(int B, int64_t* tokens, int tok_ld, const float* embed, const float* pos, float* x,
+                                 int* state, int start_id) {
+  const int tid = threadIdx.x;
+  if (tid < ST_FLAGS + DEC_MAXB) state[tid] = (tid == ST_FIN) ? -1 : 0;
+  for (int b = 0; b < B; ++b) {
+    if (tid == 0) tokens[(size_t)b * tok_ld] = start_id;
+    x[b * DMODEL + tid] = embed[(size_t)start_id * DMODEL + tid] + pos[tid];
+    x[b * DMODEL + 256 + tid] = embed[(size_t)start_id * DMODEL + 256 + tid] + pos[256 + tid];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct mrmt3_decoder {
+  int L, d, H, dff, V, maxB, maxLen, maxEnc, wdt, inner;
+  float eps;
+  void *kc, *vc;  // [L][maxB][maxLen][inner]
+  float *x, *q, *o, *g, *logits;
+  int* state;
+  // per-batch
+  mrmt3_decoder_weights w;
+  const void *ln_self[64], *w_qkv[64], *w_o_self[64], *ln_cross[64], *w_q_cross[64], *w_o_cross[64], *ln_ff[64],
+      *w_wi[64], *w_wo[64];
+  const void* cross_kv;
+  int B, encLen, eos, pad;
+  int64_t* tokens;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int captured;     // 1 = exec valid for the current (B, encLen, pointers)
+  int graph_failed;  // 1 = capture failed once; run with plain launches
+};
+
+extern "C" int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_model, int n_heads, int d_ff, int vocab,
+                                    int max_batch, int max_len, int max_enc_len, int w_dtype, float eps) {
+  MR_CHECK_ARG(out, "decoder_create: null out");
+  *out = nullptr;
+  MR_CHECK_ARG(d_model == DMODEL, "decoder_create: kernels are specialised for d_model = 512");
+  MR_CHECK_ARG(n_layers > 0 && n_layers <= 64 && max_batch > 0 && max_batch <= DEC_MAXB, "decoder_create: need 1..64 layers, batch <= 8");
+  MR_CHECK_ARG(d_ff % 8 == 0 && d_ff <= 4096 && vocab > 0 && max_len > 0 && max_enc_len > 0, "decoder_create: bad sizes");
+  MR_CHECK_ARG(w_dtype == MRMT3_F32 || w_dtype == MRMT3_BF16, "decoder_create: bad dtype");
+  mrmt3_decoder* D = new mrmt3_decoder();
+  memset(D, 0, sizeof(*D));
+  D->L = n_layers; D->d = d_model; D->H = n_heads; D->dff = d_ff; D->V = vocab; D->maxB = max_batch;
+  D->maxLen = max_len; D->maxEnc = max_enc_len; D->wdt = w_dtype; D->inner = n_heads * 64; D->eps = eps;
+  const size_t esz = w_dtype == MRMT3_BF16 ? 2 : 4;
+  const size_t cache = (size_t)n_layers * max_batch * max_len * D->inner * esz;
+  hipError_t e = hipMalloc(&D->kc, cache);
+  if (e == hipSuccess) e = hipMalloc(&D->vc, cache);
+  if (e == hipSuccess) e = hipMalloc((void**)&D->x, sizeof(float) * max_batch * DMODEL);
+  if (e == hipSuccess) e = hipMalloc((void**)&D->q, sizeof(float) * max_batch * D->inner);
+  if (e == hipSuccess) e = hipMalloc((void**)&D->o, sizeof(float) * max_batch * D->inner);
+  if (e == hipSuccess) e = hipMalloc((void**)&D->g, sizeof(float) * max_batch * d_ff);
+  if (e == hipSuccess) e = hipMalloc((void**)&D->logits, sizeof(float) * max_batch * vocab);
+  if (e == hipSuccess) e = hipMalloc((void**)&D->state, sizeof(int) * (ST_FLAGS + DEC_MAXB));
+  if (e != hipSuccess) {
+    mrmt3_set_error("decoder_create: hipMalloc failed: %s", hipGetErrorString(e));
+    mrmt3_decoder_destroy(D);
+    return MRMT3_ERR_HIP;
+  }
+  *out = D;
+  return MRMT3_OK;
+}
+
+extern "C" void mrmt3_decoder_destroy(mrmt3_decoder* D) {
+  if (!D) return;
+  if (D->exec) hipGraphExecDestroy(D->exec);
+  if (D->graph) hipGraphDestroy(D->graph);
+  void* bufs[] = {D->kc, D->vc, D->x, D->q, D->o, D->g, D->logits, D->state};
+  for (void* b : bufs) if (b) hipFree(b);
+  delete D;
+}
+
+extern "C" int mrmt3_decoder_begin(mrmt3_decoder* D, const mrmt3_decoder_weights* w, const void* cross_kv, int batch,
+                                   int enc_len, int64_t* tokens_out, int start_id, int eos_id, int pad_id,
+                                   void* stream) {
+  MR_CHECK_ARG(D && w && cross_kv && tokens_out, "decoder_begin: null pointer");
+  MR_CHECK_ARG(batch > 0 && batch <= D->maxB && enc_len > 0 && enc_len <= D->maxEnc, "decoder_begin: batch/enc_len out of range");
+  bool same = D->captured && D->B == batch && D->encLen == enc_len && D->cross_kv == cross_kv &&
+              D->tokens == tokens_out && D->eos == eos_id && D->pad == pad_id && D->w.embed == w->embed &&
+              D->w.lm_head == w->lm_head && D->w.pos == w->pos && D->w.final_ln == w->final_ln;
+  for (int l = 0; l < D->L && same; ++l)
+    same = D->w_qkv[l] == w->w_qkv[l] && D->w_wi[l] == w->w_wi[l] && D->w_wo[l] == w->w_wo[l] &&
+           D->w_o_self[l] == w->w_o_self[l] && D->w_q_cross[l] == w->w_q_cross[l] && D->w_o_cross[l] == w->w_o_cross[l];
+  D->w = *w;
+  for (int l = 0; l < D->L; ++l) {
+    D->ln_self[l] = w->ln_self[l]; D->w_qkv[l] = w->w_qkv[l]; D->w_o_self[l] = w->w_o_self[l];
+    D->ln_cross[l] = w->ln_cross[l]; D->w_q_cross[l] = w->w_q_cross[l]; D->w_o_cross[l] = w->w_o_cross[l];
+    D->ln_ff[l] = w->ln_ff[l]; D->w_wi[l] = w->w_wi[l]; D->w_wo[l] = w->w_wo[l];
+  }
+  D->cross_kv = cross_kv; D->B = batch; D->encLen = enc_len; D->tokens = tokens_out; D->eos = eos_id; D->pad = pad_id;
+  if (!same) D->captured = 0;
+  hipLaunchKernelGGL(dec_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, batch, tokens_out, D->maxLen + 1,
+                     (const float*)w->embed, w->pos, D->x, D->state, start_id);
+  MR_CHECK_LAUNCH("decoder_begin");
+  return MRMT3_OK;
+}
+
+template <typename TW>
+static int launch_step(mrmt3_decoder* D, hipStream_t s) {
+  const int B = D->B, inner = D->inner, dff = D->dff, V = D->V;
+  const size_t cache_b = (size_t)D->maxLen * inner;             // elements per batch row of a layer's cache
+  const size_t cache_l = (size_t)D->maxB * cache_b;             // elements per layer
+  const size_t attn_shm_self = (size_t)(((D->maxLen + 3) & ~3) + 64 + 8 + 256) * sizeof(float);
+  const size_t attn_shm_cross = (size_t)(((D->encLen + 3) & ~3) + 64 + 8 + 256) * sizeof(float);
+  const TW* ckv = (const TW*)D->cross_kv;
+  for (int l = 0; l < D->L; ++l) {
+    TW* kc = (TW*)D->kc + l * cache_l;
+    TW* vc = (TW*)D->vc + l * cache_l;
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 1>), dim3(ceil_div(3 * inner, 8)), dim3(256), 0, s, D->x,
+                       (const float*)D->ln_self[l], (const TW*)D->w_qkv[l], 3 * inner, B, D->eps, D->q, kc, vc, inner,
+                       cache_b, D->state);
+    hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_self, s, D->q, (const TW*)kc, (const TW*)vc,
+                       inner, cache_b, 0, D->state, D->o, inner);
+    hipLaunchKernelGGL((dec_gemv_res<TW>), dim3(ceil_div(DMODEL, 8)), dim3(256), sizeof(float) * B * inner, s, D->o,
+                       (const TW*)D->w_o_self[l], D->x, DMODEL, inner, B);
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 0>), dim3(ceil_div(inner, 8)), dim3(256), 0, s, D->x,
+                       (const float*)D->ln_cross[l], (const TW*)D->w_q_cross[l], inner, B, D->eps, D->q, (TW*)nullptr,
+                       (TW*)nullptr, inner, (size_t)0, D->state);
+    const TW* ck = ckv + (size_t)l * B * D->encLen * 2 * inner;
+    hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_cross, s, D->q, ck, ck + inner, 2 * inner,
+                       (size_t)D->encLen * 2 * inner, D->encLen, D->state, D->o, inner);
+    hipLaunchKernelGGL((dec_gemv_res<TW>), dim3(ceil_div(DMODEL, 8)), dim3(256), sizeof(float) * B * inner, s, D->o,
+                       (const TW*)D->w_o_cross[l], D->x, DMODEL, inner, B);
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 2>), dim3(ceil_div(dff, 8)), dim3(256), 0, s, D->x, (const float*)D->ln_ff[l],
+                       (const TW*)D->w_wi[l], dff, B, D->eps, D->g, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
+                       D->state);
+    hipLaunchKernelGGL((dec_gemv_res<TW>), dim3(ceil_div(DMODEL, 8)), dim3(256), sizeof(float) * B * dff, s, D->g,
+                       (const TW*)D->w_wo[l], D->x, DMODEL, dff, B);
+  }
+  hipLaunchKernelGGL((dec_norm_gemv<TW, 0>), dim3(ceil_div(V, 8)), dim3(256), 0, s, D->x, D->w.final_ln,
+                     (const TW*)D->w.lm_head, V, B, D->eps, D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
+                     D->state);
+  hipLaunchKernelGGL(dec_argmax, dim3(1), dim3(256), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
+                     (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad);
+  MR_CHECK_LAUNCH("decoder step");
+  return MRMT3_OK;
+}
+
+static int step(mrmt3_decoder* D, hipStream_t s) {
+  return D->wdt == MRMT3_BF16 ? launch_step<bf16_t>(D, s) : launch_step<float>(D, s);
+}
+
+extern "C" int mrmt3_decoder_run(mrmt3_decoder* D, int n_steps, void* stream) {
+  MR_CHECK_ARG(D && D->tokens && n_steps >= 0, "decoder_run: call decoder_begin first");
+  hipStream_t s = (hipStream_t)stream;
+  if (!D->captured && !D->graph_failed) {
+    if (D->exec) { hipGraphExecDestroy(D->exec); D->exec = nullptr; }
+    if (D->graph) { hipGraphDestroy(D->graph); D->graph = nullptr; }
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      int rc = step(D, s);
+      hipError_t e2 = hipStreamEndCapture(s, &D->graph);
+      if (rc == MRMT3_OK && e2 == hipSuccess && D->graph) e = hipGraphInstantiate(&D->exec, D->graph, nullptr, nullptr, 0);
+      else e = hipErrorUnknown;
+    }
+    if (e == hipSuccess && D->exec) D->captured = 1;
+    else { D->graph_failed = 1; (void)hipGetLastError(); }
+  }
+  for (int i = 0; i < n_steps; ++i) {
+    if (D->captured) {
+      MR_CHECK_HIP(hipGraphLaunch(D->exec, s));
+    } else {
+      int rc = step(D, s);
+      if (rc != MRMT3_OK) return rc;
+    }
+  }
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_decoder_graph_captured(const mrmt3_decoder* D) { return D ? D->captured : 0; }
+
+extern "C" int mrmt3_decoder_poll(mrmt3_decoder* D, int32_t* state_out_pinned, void* stream) {
+  MR_CHECK_ARG(D && state_out_pinned, "decoder_poll: null pointer");
+  MR_CHECK_HIP(hipMemcpyAsync(state_out_pinned, D->state, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return MRMT3_OK;
+}

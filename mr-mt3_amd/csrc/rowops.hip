@@ -351,14 +351,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   if (row >= rows) return;
   const int64_t id = token_at(ids, row, seq_len, shift, start_id, pad_id, vocab);
   const float* trow = table + (size_t)id * d;
-  const float* prow = pos + (size_t)((row % seq_len) + pos_offset) * d;
+  const float* prow = pos ? pos + (size_t)((row % seq_len) + pos_offset) * d : nullptr;
   const size_t base = (size_t)row * d;
   for (int col = lane * 4; col < d; col += 256) {
     float a[4], p[4];
     load4<float>(trow + col, a);
-    load4<float>(prow + col, p);
+    if (prow) {
+      load4<float>(prow + col, p);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] += p[e];
+      for (int e = 0; e < 4; ++e) a[e] += p[e];
+    }
     if (dc.thresh) {
       float m[4];
       drop_mask4(dc, (base + col) >> 2, m);
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
 extern "C" int mrmt3_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* x, int rows,
                                int seq_len, int d, int vocab, int shift, int start_id, int pad_id, int pos_offset,
                                float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
-  MR_CHECK_ARG(ids && table && pos && x && rows > 0 && seq_len > 0 && d % 4 == 0, "embed_fwd: bad args");
+  MR_CHECK_ARG(ids && table && x && rows > 0 && seq_len > 0 && d % 4 == 0, "embed_fwd: bad args");
   hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids,
                      table, pos, x, rows, seq_len, d, vocab, shift, start_id, pad_id, pos_offset,
                      make_drop(p_drop, seed, stream_id));

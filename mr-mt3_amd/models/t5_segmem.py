@@ -1,0 +1,14 @@
+"""`models.t5_segmem` — drop-in for the reference's V1 segment-memory model
+(models/t5_segmem.py:38-170): memory of the previous batch row prepended to the decoder input
+embeddings."""
+import torch
+
+from mrmt3.module import MT3Module
+
+
+class T5SegMem(MT3Module):
+    VARIANT = "segmem_v1"
+
+    def __init__(self, config, segmem_num_layers: int = 1, segmem_length: int = 64, compute_dtype=None):
+        super().__init__(config, segmem_num_layers=segmem_num_layers, segmem_length=segmem_length,
+                         compute_dtype=compute_dtype or torch.bfloat16)

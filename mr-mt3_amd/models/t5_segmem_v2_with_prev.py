@@ -1,0 +1,14 @@
+"""`models.t5_segmem_v2_with_prev` — drop-in for the paper's MR-MT3 model
+(models/t5_segmem_v2_with_prev.py:38-296): memory from an explicit `targets_prev` tensor in
+training, and from the previous segment's generated tokens in `generate`."""
+import torch
+
+from mrmt3.module import MT3Module
+
+
+class T5SegMemV2WithPrev(MT3Module):
+    VARIANT = "segmem_v2_with_prev"
+
+    def __init__(self, config, segmem_num_layers: int = 1, segmem_length: int = 64, compute_dtype=None):
+        super().__init__(config, segmem_num_layers=segmem_num_layers, segmem_length=segmem_length,
+                         compute_dtype=compute_dtype or torch.bfloat16)

@@ -1,0 +1,180 @@
+"""Greedy generation on the MI355X decoder (csrc/decode.hip) with the reference's output contract.
+
+  * `T5ForConditionalGeneration.generate` (models/t5.py:251-302): batched; returns int64
+    [B, 1 + steps] starting with token 0, finished rows padded with 0, stops when every row has
+    emitted EOS.
+  * `T5SegMemV2.generate` / `T5SegMemV2WithPrev.generate` (t5_segmem_v2.py:169-233,
+    t5_segmem_v2_with_prev.py:226-296): segments decoded one after the other, each conditioned on
+    the previous segment's tokens through the segment-memory encoder; returns [n_seg, max_length].
+The encoder, the segment-memory encoder and the cross-attention K/V projections run through the
+same engine kernels as training; only the token loop uses the KV-cached step graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib
+
+
+class _Weights(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("pos", C.c_void_p), ("lm_head", C.c_void_p), ("final_ln", C.c_void_p)] + \
+               [(n, C.POINTER(C.c_void_p)) for n in ("ln_self", "w_qkv", "w_o_self", "ln_cross", "w_q_cross",
+                                                     "w_o_cross", "ln_ff", "w_wi", "w_wo")]
+
+
+class Decoder:
+    """Owns one mrmt3_decoder handle (KV cache, scratch, captured graph) for a model."""
+
+    def __init__(self, model, max_batch: int, max_len: int, max_enc_len: int):
+        self.model = model
+        eng, cfg = model.engine, model.cfg
+        self.max_batch, self.max_len, self.max_enc = max_batch, max_len, max_enc_len
+        self.dt = eng.dt
+        h = C.c_void_p()
+        lib._check(lib.load().mrmt3_decoder_create(C.byref(h), cfg["num_decoder_layers"], cfg["d_model"],
+                                                   cfg["num_heads"], cfg["d_ff"], cfg["vocab_size"], max_batch,
+                                                   max_len, max_enc_len, lib.BF16 if self.dt == torch.bfloat16 else lib.F32,
+                                                   cfg["layer_norm_epsilon"]), "decoder_create")
+        self.h = h
+        self.tokens = torch.zeros(max_batch, max_len + 1, dtype=torch.int64, device=model.device)
+        self.pinned = torch.zeros(3, dtype=torch.int32).pin_memory()
+        self._wkeep = None
+        # persistent cross-attention K|V buffer: a stable address lets the captured graph be reused
+        self.ckv_buf = torch.empty(cfg["num_decoder_layers"] * max_batch * max_enc_len * 2 * eng.inner,
+                                   device=model.device, dtype=self.dt)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib.load().mrmt3_decoder_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _weights(self):
+        m, eng, f = self.model, self.model.engine, self.model.flat
+        L = m.cfg["num_decoder_layers"]
+
+        def arr(fn):
+            a = (C.c_void_p * L)(*[fn(i).data_ptr() for i in range(L)])
+            return a
+
+        b = lambda i: f"decoder.block.{i}.layer"
+        keep = dict(
+            ln_self=arr(lambda i: f.master(f"{b(i)}.0.layer_norm.weight")),
+            w_qkv=arr(lambda i: eng.W(f"decoder.{i}.qkv")),
+            w_o_self=arr(lambda i: eng.W(f"decoder.{i}.o")),
+            ln_cross=arr(lambda i: f.master(f"{b(i)}.1.layer_norm.weight")),
+            w_q_cross=arr(lambda i: eng.W(f"decoder.{i}.cq")),
+            w_o_cross=arr(lambda i: eng.W(f"decoder.{i}.co")),
+            ln_ff=arr(lambda i: f.master(f"{b(i)}.2.layer_norm.weight")),
+            w_wi=arr(lambda i: eng.W(f"decoder.{i}.wi")),
+            w_wo=arr(lambda i: eng.W(f"decoder.{i}.wo")),
+        )
+        w = _Weights()
+        w.embed = f.master("decoder_embed_tokens.weight").data_ptr()
+        w.pos = eng.pos(m.device).data_ptr()
+        w.lm_head = eng.W("lm_head").data_ptr()
+        w.final_ln = f.master("decoder.final_layer_norm.weight").data_ptr()
+        for k, a in keep.items():
+            setattr(w, k, C.cast(a, C.POINTER(C.c_void_p)))
+        self._wkeep = (keep, w)
+        return w
+
+    def cross_kv(self, enc_cat, B, Lc):
+        """[layers][B*Lc][2*inner] K|V projections of the (memory-augmented) encoder states."""
+        eng = self.model.engine
+        L = self.model.cfg["num_decoder_layers"]
+        out = self.ckv_buf[:L * B * Lc * 2 * eng.inner].view(L, B * Lc, 2 * eng.inner)
+        for i in range(L):
+            lib.gemm_nt(enc_cat, eng.W(f"decoder.{i}.ckv"), out=out[i])
+        return out
+
+    def run(self, ckv, B, Lc, max_steps, poll_every=64):
+        """Decode up to max_steps tokens for B rows; returns (tokens [B, max_len+1] view, steps run,
+        finish_step or -1)."""
+        cfg = self.model.cfg
+        l = lib.load()
+        w = self._weights()
+        self._ckv = ckv
+        lib._check(l.mrmt3_decoder_begin(self.h, C.byref(w), lib._p(ckv), B, Lc, lib._p(self.tokens),
+                                         cfg["decoder_start_token_id"], cfg["eos_token_id"], cfg["pad_token_id"],
+                                         lib._stream()), "decoder_begin")
+        done, fin = 0, -1
+        while done < max_steps:
+            n = min(poll_every, max_steps - done)
+            lib._check(l.mrmt3_decoder_run(self.h, n, lib._stream()), "decoder_run")
+            done += n
+            lib._check(l.mrmt3_decoder_poll(self.h, C.c_void_p(self.pinned.data_ptr()), lib._stream()), "decoder_poll")
+            torch.cuda.current_stream().synchronize()
+            if int(self.pinned[1]):
+                fin = int(self.pinned[2])
+                break
+        return self.tokens, done, fin
+
+    @property
+    def graph_captured(self) -> bool:
+        return bool(lib.load().mrmt3_decoder_graph_captured(self.h))
+
+
+def _decoder_for(model, B, max_len, enc_len) -> Decoder:
+    dec = getattr(model, "_decoder", None)
+    if dec is None or dec.max_batch < B or dec.max_len < max_len or dec.max_enc < enc_len or \
+            dec.dt != model.engine.dt or dec.tokens.device != model.device:
+        dec = Decoder(model, max(B, 1), max_len, enc_len)
+        model._decoder = dec
+    return dec
+
+
+@torch.no_grad()
+def generate(model, inputs, max_length=1024, poll_every=64):
+    eng, cfg = model.engine, model.cfg
+    if not inputs.is_cuda:
+        raise RuntimeError("generate needs device tensors (no CPU fallback)")
+    eng.prepare(False)
+    B, Le, d = inputs.shape
+    enc = eng.encode(inputs.float() if inputs.dtype not in (torch.float32, torch.bfloat16) else inputs)
+    if model.VARIANT == "t5":
+        out = []
+        for b0 in range(0, B, 8):   # the step kernels batch up to 8 rows
+            nb = min(8, B - b0)
+            dec = _decoder_for(model, nb, max_length, Le)
+            ckv = dec.cross_kv(enc.view(B, Le, d)[b0:b0 + nb].reshape(nb * Le, d), nb, Le)
+            toks, done, fin = dec.run(ckv, nb, Le, max_length, poll_every)
+            steps = (fin + 1) if fin >= 0 else max_length
+            out.append((toks[:nb, :steps + 1].clone(), steps))
+        if len(out) == 1:
+            return out[0][0]
+        # the reference stops when ALL rows are finished: pad shorter groups with pad_token_id
+        steps = max(s for _, s in out)
+        res = torch.full((B, steps + 1), cfg["pad_token_id"], dtype=torch.int64, device=inputs.device)
+        r = 0
+        for t, s in out:
+            res[r:r + t.shape[0], :s + 1] = t
+            r += t.shape[0]
+        return res
+    if model.VARIANT == "segmem_v1":
+        raise NotImplementedError("T5SegMem (V1) has no `generate` in the reference either (only generate_2)")
+    # segment-memory models: sequential segments, memory = previous segment's tokens
+    Ls = model.segmem_length
+    seg_ids = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
+    if model.VARIANT == "segmem_v2_with_prev":
+        seg_ids[0, 0], seg_ids[0, 1] = 1134, 1          # tie token + EOS (t5_segmem_v2_with_prev.py:257-258)
+    else:
+        seg_ids[0, 0] = 1                                # t5_segmem_v2.py:199
+    dec = _decoder_for(model, 1, max_length, Le + Ls)
+    outs = []
+    for i in range(B):
+        mem = eng.segmem(seg_ids, 1, max_length).view(1, max_length, d)[:, :Ls]
+        cur = torch.cat([enc.view(B, Le, d)[i:i + 1], mem], 1).contiguous().view(Le + Ls, d)
+        ckv = dec.cross_kv(cur, 1, Le + Ls)
+        toks, done, fin = dec.run(ckv, 1, Le + Ls, max_length, poll_every)
+        steps = (fin + 1) if fin >= 0 else max_length
+        row = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
+        n = min(steps + 1, max_length)                   # F.pad(..., max_length - len) truncates (:287-291)
+        row[0, :n] = toks[0, :n]
+        outs.append(row)
+        seg_ids = row
+    return torch.cat(outs, 0)

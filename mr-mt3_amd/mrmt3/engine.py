@@ -1,0 +1,368 @@
+"""Forward / backward of the MR-MT3 encoder–decoder as an explicit tape over the C-ABI kernels.
+
+This is the host-side wiring that the reference gets from HF `T5Block` + autograd
+(`models/t5.py:99-180,478-702`, `models/t5_segmem*.py`): every sublayer is a short, fixed sequence
+of kernel launches, and the backward is written out by hand in reverse order so that
+  * activations are kept in the dtype the next kernel consumes (bf16 GEMM operands, fp32 residual
+    stream and statistics),
+  * weight gradients accumulate straight into the flat gradient buffer (`FlatParams.G`),
+  * a per-layer callback can start the RCCL all-reduce of finished gradient slices while the rest of
+    the backward still runs (`on_layer_done`).
+
+Residual-stream convention: a sublayer returns its un-dropped output `y`; the NEXT fused kernel
+(`add_rmsnorm`) applies dropout to `y`, adds it to the residual `x` and normalises — one pass over
+the row for three reference ops (`hidden + dropout(sublayer)`, then `T5LayerNorm`).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib
+from .params import FlatParams
+from .synthetic import sinusoid_table
+
+
+class Tape:
+    """Saved tensors of one forward pass (dropped as soon as backward has consumed them)."""
+
+    def __init__(self):
+        self.ops = []
+
+    def push(self, **kw):
+        self.ops.append(kw)
+
+    def pop(self):
+        return self.ops.pop()
+
+
+class Engine:
+    def __init__(self, cfg: dict, flat: FlatParams, variant: str = "t5", segmem_length: int = 64,
+                 segmem_num_layers: int = 0, compute_dtype=torch.bfloat16, max_pos: int = 5000):
+        self.cfg, self.flat, self.variant = cfg, flat, variant
+        self.segmem_length, self.segmem_num_layers = segmem_length, segmem_num_layers
+        self.dt = compute_dtype
+        self.d, self.H, self.dff, self.V = cfg["d_model"], cfg["num_heads"], cfg["d_ff"], cfg["vocab_size"]
+        self.inner = cfg["d_kv"] * self.H
+        assert cfg["d_kv"] == 64, "kernels are specialised for d_kv = 64"
+        self.eps = cfg["layer_norm_epsilon"]
+        self.max_pos = max_pos
+        self._pos = None
+        self._stream_ctr = 0
+        self.seed = 365
+        self.y_dtype = torch.float32   # dtype of sublayer outputs entering the residual add
+
+    # ---- helpers ---------------------------------------------------------------------------------------
+    def pos(self, device):
+        if self._pos is None or self._pos.device != device:
+            self._pos = sinusoid_table(self.max_pos, self.d).to(device).contiguous()
+        return self._pos
+
+    def _sid(self):
+        self._stream_ctr += 1
+        return self._stream_ctr
+
+    def W(self, name):
+        return self.flat.W(name, self.dt)
+
+    def ln(self, key):
+        return self.flat.master(key)
+
+    def prepare(self, training: bool):
+        if self.dt == torch.bfloat16:
+            self.flat.refresh_shadows(need_transposed=training)
+        elif training:
+            raise RuntimeError("backward is implemented for the bf16 compute path only")
+
+    # ---- one T5Stack (models/t5.py:507-702) ----------------------------------------------------------
+    def stack_fwd(self, prefix, x, B, L, n_layers, is_decoder, enc=None, Le=0, p=0.0, tape=None):
+        """x: [B*L, d] fp32 (embeddings + sinusoid, dropout already applied).
+        enc: [B*Le, d] compute-dtype encoder states for cross-attention.  Returns the final-normed
+        (and dropped) states [B*L, d] in the compute dtype."""
+        f, dt, H, inner, eps = self.flat, self.dt, self.H, self.inner, self.eps
+        keep = tape is not None
+        y = None
+        sy = 0
+        for i in range(n_layers):
+            b = f"{prefix}.block.{i}.layer"
+            # -- self attention
+            s_in = sy
+            x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.0.layer_norm.weight"), eps, dt, write_x1=True,
+                                              p=p, seed=self.seed, stream_y=s_in, x1=None if keep else x)
+            qkv = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.qkv"))
+            s_att = self._sid()
+            o, lse = lib.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, L, L,
+                                  is_decoder, p=p, seed=self.seed, stream_id=s_att, want_lse=keep)
+            y = lib.gemm_nt(o, self.W(f"{prefix}.{i}.o"), out_dtype=self.y_dtype)
+            sy = self._sid()
+            if keep:
+                tape.push(kind="self", i=i, x1=x, xn=xn, rstd=rstd, qkv=qkv, o=o, lse=lse, s_in=s_in, s_att=s_att)
+            ff = 1
+            if is_decoder and enc is not None:
+                s_in = sy
+                x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.1.layer_norm.weight"), eps, dt,
+                                                  p=p, seed=self.seed, stream_y=s_in, x1=None if keep else x)
+                q = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.cq"))
+                kv = lib.gemm_nt(enc, self.W(f"{prefix}.{i}.ckv"))
+                s_att = self._sid()
+                o, lse = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, L, Le, False, p=p, seed=self.seed,
+                                      stream_id=s_att, want_lse=keep)
+                y = lib.gemm_nt(o, self.W(f"{prefix}.{i}.co"), out_dtype=self.y_dtype)
+                sy = self._sid()
+                if keep:
+                    tape.push(kind="cross", i=i, x1=x, xn=xn, rstd=rstd, q=q, kv=kv, o=o, lse=lse, s_in=s_in,
+                              s_att=s_att)
+                ff = 2
+            # -- gated-GELU feed forward
+            s_in = sy
+            x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.{ff}.layer_norm.weight"), eps, dt,
+                                              p=p, seed=self.seed, stream_y=s_in, x1=None if keep else x)
+            h = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.wi"))
+            s_g = self._sid()
+            g = lib.geglu_fwd(h, p=p, seed=self.seed, stream_id=s_g)
+            y = lib.gemm_nt(g, self.W(f"{prefix}.{i}.wo"), out_dtype=self.y_dtype)
+            sy = self._sid()
+            if keep:
+                tape.push(kind="ff", i=i, ff=ff, x1=x, xn=xn, rstd=rstd, h=h, g=g, s_in=s_in, s_g=s_g)
+        s_out = self._sid()
+        x, out, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{prefix}.final_layer_norm.weight"), eps, dt, p=p,
+                                           seed=self.seed, stream_y=sy, stream_out=s_out, out_drop=True,
+                                           x1=None if keep else x)
+        if keep:
+            tape.push(kind="final", x1=x, rstd=rstd, s_in=sy, s_out=s_out, prefix=prefix, n_layers=n_layers,
+                      is_decoder=is_decoder, B=B, L=L, Le=Le, enc=enc, p=p)
+        return out
+
+    def stack_bwd(self, tape, d_out, d_enc=None, on_layer_done=None):
+        """d_out: fp32 [B*L, d] gradient w.r.t. the stack output.  Accumulates weight grads into
+        flat.G, adds cross-attention gradients into d_enc (fp32 [B*Le, d]) and returns the gradient
+        w.r.t. the stack input x."""
+        f = self.flat
+        fin = tape.pop()
+        assert fin["kind"] == "final"
+        prefix, n_layers, is_dec = fin["prefix"], fin["n_layers"], fin["is_decoder"]
+        B, L, Le, enc, p = fin["B"], fin["L"], fin["Le"], fin["enc"], fin["p"]
+        H, inner, seed = self.H, self.inner, self.seed
+        has_y = n_layers > 0
+        dx, dy = lib.add_rmsnorm_bwd(d_out, None, fin["x1"], fin["rstd"], self.ln(f"{prefix}.final_layer_norm.weight"),
+                                     f.grad(f"{prefix}.final_layer_norm.weight"), want_dy=has_y, p=p, seed=seed,
+                                     stream_y=fin["s_in"], stream_out=fin["s_out"], out_drop=True)
+        for i in reversed(range(n_layers)):
+            b = f"{prefix}.block.{i}.layer"
+            t = tape.pop()
+            assert t["kind"] == "ff" and t["i"] == i
+            ff = t["ff"]
+            lib.gemm_tn(dy, t["g"], f.GW(f"{prefix}.{i}.wo"), accumulate=True)
+            dg = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.wo"))
+            dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, stream_id=t["s_g"])
+            lib.gemm_tn(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"), accumulate=True)
+            dxn = lib.gemm_nt(dh, f.WT(f"{prefix}.{i}.wi"), out_dtype=torch.float32)
+            dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
+                                         f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
+                                         dx1=dx)
+            if ff == 2:
+                t = tape.pop()
+                assert t["kind"] == "cross"
+                lib.gemm_tn(dy, t["o"], f.GW(f"{prefix}.{i}.co"), accumulate=True)
+                do = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.co"))
+                dq = torch.empty_like(t["q"])
+                dkv = torch.empty_like(t["kv"])
+                kv = t["kv"]
+                lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
+                             dkv[:, inner:], B, H, L, Le, False, p=p, seed=seed, stream_id=t["s_att"])
+                lib.gemm_tn(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"), accumulate=True)
+                lib.gemm_tn(dkv, enc, f.GW(f"{prefix}.{i}.ckv"), accumulate=True)
+                lib.gemm_nt(dkv, f.WT(f"{prefix}.{i}.ckv"), out=d_enc, accumulate=True)
+                dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=torch.float32)
+                dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
+                                             f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
+                                             dx1=dx)
+            t = tape.pop()
+            assert t["kind"] == "self" and t["i"] == i
+            lib.gemm_tn(dy, t["o"], f.GW(f"{prefix}.{i}.o"), accumulate=True)
+            do = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.o"))
+            qkv = t["qkv"]
+            dqkv = torch.empty_like(qkv)
+            lib.attn_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], t["o"], do, t["lse"],
+                         dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, H, L, L, is_dec, p=p,
+                         seed=seed, stream_id=t["s_att"])
+            lib.gemm_tn(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"), accumulate=True)
+            dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=torch.float32)
+            dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
+                                         f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed,
+                                         stream_y=t["s_in"], dx1=dx)
+            if on_layer_done is not None:
+                on_layer_done(prefix, i)
+        return dx
+
+    # ---- model pieces ------------------------------------------------------------------------------------
+    def _act(self, t):
+        """torch tensor -> contiguous compute-dtype 2-D operand."""
+        t = t.contiguous()
+        if t.dtype != self.dt:
+            out = torch.empty(t.shape, device=t.device, dtype=self.dt)
+            lib.cast(t.view(-1), out.view(-1))
+            t = out
+        return t
+
+    def encode(self, mel, p=0.0, tape=None):
+        """proj -> + sinusoid -> dropout -> encoder stack (models/t5.py:122-136).  mel [B,Le,d]."""
+        B, Le, d = mel.shape
+        mel2 = self._act(mel.reshape(B * Le, d))
+        src = lib.gemm_nt(mel2, self.W("proj"), out_dtype=self.y_dtype)
+        s_emb = self._sid()
+        x = lib.addpos_fwd(src, self.pos(mel.device), Le, p=p, seed=self.seed, stream_id=s_emb)
+        if tape is not None:
+            tape.push(kind="enc_in", mel=mel2, s_emb=s_emb, p=p)
+        return self.stack_fwd("encoder", x, B, Le, self.cfg["num_layers"], False, p=p, tape=tape)
+
+    def encode_bwd(self, tape, d_enc_out, on_layer_done=None):
+        dx = self.stack_bwd(tape, d_enc_out, on_layer_done=on_layer_done)
+        t = tape.pop()
+        assert t["kind"] == "enc_in"
+        dsrc = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, stream_id=t["s_emb"])
+        lib.gemm_tn(dsrc, t["mel"], self.flat.GW("proj"), accumulate=True)
+
+    def segmem(self, ids, B, L, tape=None):
+        """embed -> segmem_proj -> 1-layer bidirectional encoder, dropout 0
+        (models/t5_segmem.py:56-66, models/t5_segmem_v2_with_prev.py:121-123; the positional call
+        `self.segmem_encoder(segmem_embeds)` routes the embeddings through `embed_tokens` =
+        segmem_proj).  Returns all L positions [B*L, d] in the compute dtype."""
+        f = self.flat
+        emb = lib.embed_fwd(ids.reshape(-1), f.master("decoder_embed_tokens.weight"), None, L, shift=False,
+                            pad_id=self.cfg["pad_token_id"])
+        emb_a = self._act(emb)
+        src = lib.gemm_nt(emb_a, self.W("segmem_proj"), out_dtype=self.y_dtype)
+        x = lib.addpos_fwd(src, self.pos(ids.device), L)
+        if tape is not None:
+            tape.push(kind="seg_in", ids=ids.reshape(-1), emb=emb_a, L=L)
+        return self.stack_fwd("segmem_encoder", x, B, L, self.segmem_num_layers, False, p=0.0, tape=tape)
+
+    def segmem_bwd(self, tape, d_mem_full):
+        dx = self.stack_bwd(tape, d_mem_full)
+        t = tape.pop()
+        assert t["kind"] == "seg_in"
+        dsrc = lib.dropmask_cast(dx)
+        lib.gemm_tn(dsrc, t["emb"], self.flat.GW("segmem_proj"), accumulate=True)
+        demb = lib.gemm_nt(dsrc, self.flat.WT("segmem_proj"), out_dtype=torch.float32)
+        lib.embed_bwd(t["ids"], demb, self.flat.grad("decoder_embed_tokens.weight"), t["L"], shift=False,
+                      pad_id=self.cfg["pad_token_id"])
+
+    @staticmethod
+    def prev_row_ids(labels, start_id, pad_id):
+        """V1/V2 memory ids (models/t5_segmem_v2.py:126-133) from the shifted decoder inputs."""
+        B, L = labels.shape
+        dec = torch.cat([labels.new_full((B, 1), start_id), labels[:, :-1]], 1)
+        dec = dec.masked_fill(dec == -100, pad_id)
+        seg = torch.cat([dec[:, 1:], dec.new_zeros(B, 1)], 1)
+        dummy = dec.new_zeros(1, L)
+        dummy[0, 0] = 1
+        return torch.cat([dummy, seg[:-1]], 0).contiguous()
+
+    # ---- full forward / backward --------------------------------------------------------------------------
+    def forward(self, mel, labels, targets_prev=None, training=False, need_grad=False):
+        """Returns (logits [B, Ld, V] fp32, tape or None).  Mirrors get_model_outputs of the four
+        reference model classes (models/t5.py:99-180, t5_segmem.py:68-170, t5_segmem_v2.py:64-167,
+        t5_segmem_v2_with_prev.py:60-153)."""
+        cfg, f = self.cfg, self.flat
+        if not mel.is_cuda:
+            raise RuntimeError("MR-MT3 MI355X path needs device tensors (no CPU fallback)")
+        self.prepare(need_grad)
+        p = float(cfg["dropout_rate"]) if training else 0.0
+        tape = Tape() if need_grad else None
+        B, Le, d = mel.shape
+        Ld = labels.shape[1]
+        labels = labels.contiguous()
+        Ls = self.segmem_length
+        enc = self.encode(mel, p=p, tape=tape)                                  # [B*Le, d]
+        table = f.master("decoder_embed_tokens.weight")
+        start, pad = cfg["decoder_start_token_id"], cfg["pad_token_id"]
+        pos = self.pos(mel.device)
+        variant = self.variant
+        mem = None
+        if variant != "t5":
+            if variant == "segmem_v2_with_prev":
+                assert targets_prev is not None
+                targets_prev.masked_fill_(targets_prev == -100, pad)             # in place, like the reference (:119)
+                ids = targets_prev.contiguous()
+            else:
+                ids = self.prev_row_ids(labels, start, pad)
+            Lm = ids.shape[1]
+            mem_full = self.segmem(ids, B, Lm, tape=tape)                        # [B*Lm, d]
+            mem = mem_full.view(B, Lm, d)[:, :Ls]
+        s_emb = self._sid()
+        if variant == "segmem_v1":
+            # memory is PREPENDED to the decoder input embeddings (t5_segmem.py:138-160)
+            emb = lib.embed_fwd(labels.view(-1), table, None, Ld, shift=True, start_id=start, pad_id=pad)
+            xin = torch.cat([mem.float(), emb.view(B, Ld, d)], 1).contiguous()
+            Lx = Ld + Ls
+            x = lib.addpos_fwd(xin.view(B * Lx, d), pos, Lx, p=p, seed=self.seed, stream_id=s_emb)
+            enc_cat, Lc = enc, Le
+        else:
+            Lx = Ld
+            x = lib.embed_fwd(labels.view(-1), table, pos, Ld, shift=True, start_id=start, pad_id=pad, p=p,
+                              seed=self.seed, stream_id=s_emb)
+            if mem is not None:
+                enc_cat = torch.cat([enc.view(B, Le, d), mem], 1).contiguous().view(-1, d)
+                Lc = Le + Ls
+            else:
+                enc_cat, Lc = enc, Le
+        if tape is not None:
+            tape.push(kind="dec_in", s_emb=s_emb, p=p, labels=labels, B=B, Le=Le, Ld=Ld, Lx=Lx, Lc=Lc,
+                      Lm=(ids.shape[1] if variant != "t5" else 0))
+        dec = self.stack_fwd("decoder", x, B, Lx, cfg["num_decoder_layers"], True, enc=enc_cat, Le=Lc, p=p, tape=tape)
+        if variant == "segmem_v1":
+            dec = dec.view(B, Lx, d)[:, Ls:].contiguous().view(B * Ld, d)
+        logits = lib.gemm_nt(dec, self.W("lm_head"), out_dtype=torch.float32)    # [B*Ld, V]
+        if tape is not None:
+            tape.push(kind="head", dec=dec)
+        return logits.view(B, Ld, self.V), tape
+
+    def backward(self, tape, dlogits, on_layer_done=None):
+        """dlogits: [B*Ld, V] (bf16 preferred; fp32 is cast).  Accumulates into flat.G."""
+        f, cfg, d = self.flat, self.cfg, self.d
+        variant, Ls = self.variant, self.segmem_length
+        t = tape.pop()
+        assert t["kind"] == "head"
+        dl = dlogits.reshape(-1, self.V)
+        if dl.dtype != torch.bfloat16:
+            dl = self._act(dl)
+        lib.gemm_tn(dl, t["dec"], f.GW("lm_head"), accumulate=True)
+        d_dec = lib.gemm_nt(dl, f.WT("lm_head"), out_dtype=torch.float32)
+        if on_layer_done is not None:
+            on_layer_done("lm_head", 0)
+        # peek the decoder-input record (it sits below the decoder stack's records)
+        din = next(o for o in reversed(tape.ops) if o["kind"] == "dec_in")
+        B, Le, Ld, Lx, Lc = din["B"], din["Le"], din["Ld"], din["Lx"], din["Lc"]
+        if variant == "segmem_v1":
+            full = torch.zeros(B, Lx, d, device=d_dec.device, dtype=torch.float32)
+            full[:, Ls:] = d_dec.view(B, Ld, d)
+            d_dec = full.view(B * Lx, d)
+        d_enc_cat = torch.zeros(B * Lc, d, device=d_dec.device, dtype=torch.float32)
+        dx = self.stack_bwd(tape, d_dec, d_enc=d_enc_cat, on_layer_done=on_layer_done)
+        t = tape.pop()
+        assert t["kind"] == "dec_in"
+        table_g = f.grad("decoder_embed_tokens.weight")
+        start, pad = cfg["decoder_start_token_id"], cfg["pad_token_id"]
+        d_mem = None
+        if variant == "segmem_v1":
+            dxm = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, stream_id=t["s_emb"]).float().view(B, Lx, d)
+            d_mem = dxm[:, :Ls]
+            lib.embed_bwd(t["labels"].view(-1), dxm[:, Ls:].contiguous().view(-1, d), table_g, Ld, shift=True,
+                          start_id=start, pad_id=pad)
+            d_enc = d_enc_cat
+        else:
+            lib.embed_bwd(t["labels"].view(-1), dx, table_g, Ld, shift=True, start_id=start, pad_id=pad, p=t["p"],
+                          seed=self.seed, stream_id=t["s_emb"])
+            if variant != "t5":
+                dcat = d_enc_cat.view(B, Lc, d)
+                d_enc = dcat[:, :Le].contiguous().view(-1, d)
+                d_mem = dcat[:, Le:]
+            else:
+                d_enc = d_enc_cat
+        if d_mem is not None:
+            Lm = t["Lm"]
+            d_full = torch.zeros(B, Lm, d, device=dx.device, dtype=torch.float32)
+            d_full[:, :Ls] = d_mem
+            self.segmem_bwd(tape, d_full.view(B * Lm, d))
+        self.encode_bwd(tape, d_enc, on_layer_done=on_layer_done)
+        assert not tape.ops, [o["kind"] for o in tape.ops]

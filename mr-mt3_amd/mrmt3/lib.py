@@ -47,7 +47,8 @@ _SIGS = {
     "mrmt3_cast": (ci, [vp, ci, vp, ci, csz, vp]),
     "mrmt3_decoder_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci, ci, ci, cf]),
     "mrmt3_decoder_destroy": (None, [vp]),
-    "mrmt3_decoder_begin": (ci, [vp, vp, vp, vp, ci, ci, vp, ci, ci, ci, ci, vp]),
+    "mrmt3_decoder_begin": (ci, [vp, vp, vp, ci, ci, vp, ci, ci, ci, vp]),
+    "mrmt3_decoder_graph_captured": (ci, [vp]),
     "mrmt3_decoder_run": (ci, [vp, ci, vp]),
     "mrmt3_decoder_poll": (ci, [vp, vp, vp]),
 }
