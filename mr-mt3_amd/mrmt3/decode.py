@@ -41,6 +41,8 @@ class Decoder:
         self.tokens = torch.zeros(max_batch, max_len + 1, dtype=torch.int64, device=model.device)
         self.pinned = torch.zeros(3, dtype=torch.int32).pin_memory()
         self._wkeep = None
+        # hipGraph capture is illegal on the legacy default stream: the token loop runs on its own stream
+        self.stream = torch.cuda.Stream(device=model.device)
         # persistent cross-attention K|V buffer: a stable address lets the captured graph be reused
         self.ckv_buf = torch.empty(cfg["num_decoder_layers"] * max_batch * max_enc_len * 2 * eng.inner,
                                    device=model.device, dtype=self.dt)
@@ -99,6 +101,14 @@ class Decoder:
         l = lib.load()
         w = self._weights()
         self._ckv = ckv
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self._run_on_stream(l, w, ckv, B, Lc, max_steps, poll_every, cfg)
+        cur.wait_stream(self.stream)
+        return out
+
+    def _run_on_stream(self, l, w, ckv, B, Lc, max_steps, poll_every, cfg):
         lib._check(l.mrmt3_decoder_begin(self.h, C.byref(w), lib._p(ckv), B, Lc, lib._p(self.tokens),
                                          cfg["decoder_start_token_id"], cfg["eos_token_id"], cfg["pad_token_id"],
                                          lib._stream()), "decoder_begin")
@@ -158,7 +168,7 @@ def generate(model, inputs, max_length=1024, poll_every=64):
     if model.VARIANT == "segmem_v1":
         raise NotImplementedError("T5SegMem (V1) has no `generate` in the reference either (only generate_2)")
     # segment-memory models: sequential segments, memory = previous segment's tokens
-    Ls = model.segmem_length
+    Ls = min(model.segmem_length, max_length)            # `[:, :segmem_length]` of a max_length-long sequence
     seg_ids = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
     if model.VARIANT == "segmem_v2_with_prev":
         seg_ids[0, 0], seg_ids[0, 1] = 1134, 1          # tie token + EOS (t5_segmem_v2_with_prev.py:257-258)
