@@ -1,0 +1,216 @@
+"""bench.py — MR-MT3 hot path on MI355X: training segments/sec (+ inference real-time factor).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimizer step over one batch of synthetic audio per GPU, everything inside the
+timed region: log-mel frontend (HIP) -> T5-small encoder/decoder forward (dropout ON) -> fused CE ->
+hand-written backward overlapped with the RCCL gradient all-reduce -> one-launch AdamW.
+Workload at N=1 = BASELINE.json configs[1]: MT3Net (T5-small) bf16, batch 64 segments of 2.048 s
+(32768 samples @16 kHz -> 256 mel frames), 1024-token targets, golden-recipe weights.
+Data parallel: every rank draws its own 64 segments (weak scaling); value = N*64*K / max-rank time.
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel family, measured with
+events on the launch stream in an instrumented pass of the same steps), `cpu_baseline` (the CPU
+oracle timed on this host, N=1 only) and `inference` (greedy decode RTF, hipGraph replayed steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "mr-mt3_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_SEG_FWD_BWD = 225.1e9   # MT3Net, SURVEY §8d (full causal square counted, as the reference computes it)
+SEG_SECONDS = 32768 / 16000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="segments per GPU per step")
+    ap.add_argument("--variant", default="t5", choices=["t5", "segmem_v2", "segmem_v2_with_prev"])
+    ap.add_argument("--decode-tokens", type=int, default=1024)
+    ap.add_argument("--decode-batch", type=int, default=8)
+    ap.add_argument("--no-inference", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def build_model(variant, dev, dtype=torch.bfloat16):
+    from mrmt3.synthetic import T5_SMALL
+    if variant == "t5":
+        from models.t5 import T5ForConditionalGeneration
+        m = T5ForConditionalGeneration(T5_SMALL, compute_dtype=dtype)
+    elif variant == "segmem_v2":
+        from models.t5_segmem_v2 import T5SegMemV2
+        m = T5SegMemV2(T5_SMALL, 1, 64, compute_dtype=dtype)
+    else:
+        from models.t5_segmem_v2_with_prev import T5SegMemV2WithPrev
+        m = T5SegMemV2WithPrev(T5_SMALL, 1, 64, compute_dtype=dtype)
+    return m.load_golden().to(dev)
+
+
+def roofline_pass(trainer, audio, labels, prev, steps):
+    """Instrumented repeat of the timed steps: events around every heavy launch on the launch stream."""
+    from mrmt3 import lib
+    lib.PROFILE = []
+    for _ in range(steps):
+        trainer.train_step(audio, labels, prev, audio=True)
+    torch.cuda.synchronize()
+    fam = {}
+    for name, work, unit, e0, e1 in lib.PROFILE:
+        f = fam.setdefault(name, dict(ms=0.0, work=0.0, n=0, unit=unit))
+        f["ms"] += e0.elapsed_time(e1)
+        f["work"] += work
+        f["n"] += 1
+    lib.PROFILE = None
+    return fam
+
+
+def cpu_baseline(seconds):
+    """The CPU oracle (port of the reference path) timed on this host: fwd + CE + backward, B=1."""
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_audio, synth_labels
+    from oracle import logmel_ref, t5_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in golden_weights(T5_SMALL).items()}
+    audio = synth_audio(1)
+    lab = torch.from_numpy(synth_labels(1))
+    n, t0 = 0, time.perf_counter()
+    while True:
+        mel = torch.from_numpy(logmel_ref.logmel_segments(audio))
+        loss = t5_ref.ce_loss(t5_ref.forward_logits(sd, T5_SMALL, mel, lab), lab)
+        loss.backward()
+        n += 1
+        if time.perf_counter() - t0 > seconds or n >= 64:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="segments/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d x (log-mel + fwd + CE + bwd) of 1 segment (no optimizer, no dropout), fp32 torch CPU oracle, %.1f s" % (n, dt))
+
+
+def inference_rtf(dev, tokens, batch):
+    """Greedy decode of `batch` segments x `tokens` tokens (EOS suppressed so every step runs)."""
+    from contrib import spectrograms as sp
+    from mrmt3.synthetic import synth_audio
+    m = build_model("t5", dev).eval()
+    with torch.no_grad():
+        m.flat.master("lm_head.weight")[1].zero_()
+    audio = torch.from_numpy(synth_audio(batch, seed=366)).to(dev)
+    out = {}
+    for name, nb in (("b1", 1), ("b%d" % batch, batch)):
+        a = audio[:nb]
+        for rep in range(2):      # first pass captures the graph
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mel = sp.logmel_segments(a, out_bf16=True)
+            ids = m.generate(mel, max_length=tokens)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert ids.shape == (nb, tokens + 1)
+        out[name] = dict(segments=nb, tokens=tokens, seconds=dt, rtf=dt / (nb * SEG_SECONDS),
+                         ms_per_token_step=1e3 * dt / tokens, graph=bool(m._decoder.graph_captured))
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from mrmt3 import lib
+    lib.load()
+    from mrmt3.synthetic import synth_audio, synth_labels
+    from mrmt3.trainer import Trainer
+    from utils import cosine_warmup_lambda
+
+    B = args.batch
+    model = build_model(args.variant, dev)
+    trainer = Trainer(model, lr=2e-4, lr_lambda=cosine_warmup_lambda(64500, 1289 * 800, min_lr=1e-4))
+    audio = torch.from_numpy(synth_audio(B, seed=365 + rank)).to(dev)
+    labels = torch.from_numpy(synth_labels(B, seed=365 + rank)).to(dev)
+    prev = torch.from_numpy(synth_labels(B, seed=1365 + rank)).to(dev) if args.variant == "segmem_v2_with_prev" else None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    seg_per_s = world * B * args.steps / dt
+
+    res = {
+        "metric": "train segments/sec (T5-small MT3Net, 256-frame mel, 1024-token target; log-mel + fwd + bwd + AdamW)",
+        "value": seg_per_s, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %s bf16, %d segments/GPU/step of 32768 samples @16kHz -> 256x512 mel, "
+                               "1024-token targets, dropout 0.1 on, golden-recipe weights" % (args.variant, B),
+                   "segments_per_gpu": B, "global_segments": B * world, "parallelism": "dp%d" % world,
+                   "audio_seconds_per_step": B * world * SEG_SECONDS},
+        "final_loss": final_loss,
+        "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
+    }
+    if rank == 0 and not args.no_roofline:
+        fam = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), max(1, min(args.steps, 3)))
+        total = sum(f["ms"] for f in fam.values())
+        dom = max((k for k in fam if fam[k]["unit"] == "FLOP"), key=lambda k: fam[k]["ms"])
+        f = fam[dom]
+        achieved = f["work"] / (f["ms"] * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                           "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
+                           "families_ms_per_step": {k: v["ms"] / max(1, min(args.steps, 3)) for k, v in fam.items()},
+                           "families_achieved": {k: (v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "FLOP" else 1e9))
+                                                 for k, v in fam.items()},
+                           "instrumented_ms_total_per_step": total / max(1, min(args.steps, 3))}
+    sync()
+    if rank == 0 and not args.no_inference:
+        del trainer, model
+        torch.cuda.empty_cache()
+        res["inference"] = inference_rtf(dev, args.decode_tokens, args.decode_batch)
+        res["inference"]["metric"] = "real-time factor = wall seconds / audio seconds (greedy, bf16, KV cache, hipGraph)"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    sync()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,30 @@ def load():
     return lib
 
 
+# Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, the wrappers of
+# the heavy kernels bracket their launch with events on the current stream and append
+# (family, algorithmic_work, unit, start_event, end_event).
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, family, work, unit):
+        self.args = (family, work, unit)
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append(self.args + (self.e0, self.e1))
+        return False
+
+
 def _check(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"{what} failed (code {rc}): {load().mrmt3_last_error().decode()}")
@@ -123,10 +147,11 @@ def logmel(audio, tables, valid_frames=None, normalize=True, out_bf16=False):
     hop, n_mels = tables["hop"], tables["n_mels"]
     frames = -(-n // hop)
     out = torch.empty(B, frames, n_mels, device=audio.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    _check(load().mrmt3_logmel_fwd(_p(audio), B, n, hop, _p(tables["window"]), _p(tables["twiddle"]),
-                                   _p(tables["fb_start"]), _p(tables["fb_cnt"]), _p(tables["fb_w"]), n_mels,
-                                   tables["max_taps"], _p(valid_frames), int(normalize), int(out_bf16), _p(out),
-                                   _stream()), "logmel_fwd")
+    with _Timed("logmel", audio.numel() * 4 + out.numel() * out.element_size(), "B"):
+        _check(load().mrmt3_logmel_fwd(_p(audio), B, n, hop, _p(tables["window"]), _p(tables["twiddle"]),
+                                       _p(tables["fb_start"]), _p(tables["fb_cnt"]), _p(tables["fb_w"]), n_mels,
+                                       tables["max_taps"], _p(valid_frames), int(normalize), int(out_bf16), _p(out),
+                                       _stream()), "logmel_fwd")
     return out
 
 
@@ -139,8 +164,9 @@ def gemm_nt(a, b, out=None, out_dtype=None, accumulate=False):
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
     assert out.stride(1) == 1
-    _check(load().mrmt3_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _dt(a),
-                                _dt(out), int(accumulate), _stream()), "gemm_nt")
+    with _Timed("gemm_nt_bf16" if a.dtype == torch.bfloat16 else "gemm_nt_f32", 2.0 * M * N * K, "FLOP"):
+        _check(load().mrmt3_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _dt(a),
+                                    _dt(out), int(accumulate), _stream()), "gemm_nt")
     return out
 
 
@@ -165,8 +191,9 @@ def gemm_tn(a, b, out, accumulate=False):
     lib = load()
     nbytes = lib.mrmt3_gemm_tn_workspace_bytes(M, N1, N2)
     ws = workspace(nbytes, a.device)
-    _check(lib.mrmt3_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N1, N2,
-                             int(accumulate), _p(ws), ws.numel(), _stream()), "gemm_tn")
+    with _Timed("gemm_tn_bf16", 2.0 * M * N1 * N2, "FLOP"):
+        _check(lib.mrmt3_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N1, N2,
+                                 int(accumulate), _p(ws), ws.numel(), _stream()), "gemm_tn")
     return out
 
 
@@ -202,19 +229,22 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse
     _dev(q, k, v)
     o = torch.empty(B * Lq, H * 64, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
-    _check(load().mrmt3_attn_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-                                 _p(lse), B, H, Lq, Lk, int(causal), _dt(q), p, seed, stream_id, _stream()),
-           "attn_fwd")
+    # algorithmic FLOPs count the full (unskipped) square, as the reference computes it
+    with _Timed("attn_fwd", 4.0 * B * H * Lq * Lk * 64, "FLOP"):
+        _check(load().mrmt3_attn_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                     _p(lse), B, H, Lq, Lk, int(causal), _dt(q), p, seed, stream_id, _stream()),
+               "attn_fwd")
     return o, lse
 
 
 def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0):
     _dev(q, k, v, o, d_o, lse, dq, dk, dv)
     delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    _check(load().mrmt3_attn_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-                                 _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk),
-                                 dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, int(causal), p, seed, stream_id,
-                                 _stream()), "attn_bwd")
+    with _Timed("attn_bwd", 8.0 * B * H * Lq * Lk * 64, "FLOP"):
+        _check(load().mrmt3_attn_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                     _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk),
+                                     dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, int(causal), p, seed,
+                                     stream_id, _stream()), "attn_bwd")
     return dq, dk, dv
 
 
