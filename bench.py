@@ -87,7 +87,9 @@ def cpu_baseline(seconds):
     """The CPU oracle (port of the reference path) timed on this host: fwd + CE + backward, B=1."""
     from mrmt3.synthetic import T5_SMALL, golden_weights, synth_audio, synth_labels
     from oracle import logmel_ref, t5_ref
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and collapses) far below the host's core count on
+    # T5-small sized matmuls: use at most 16 threads and report that number as `cores`.
+    cores = max(1, min(os.cpu_count() or 1, 16))
     torch.set_num_threads(cores)
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in golden_weights(T5_SMALL).items()}
     audio = synth_audio(1)
