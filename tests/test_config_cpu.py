@@ -1,0 +1,108 @@
+"""Hydra-compatible composer (mrmt3.hydra_lite) on a config tree shaped like the reference's
+(`config/config_slakh_segmem.yaml` + `config/model/*.yaml`): defaults list, `${a.b}` and
+`${hydra:runtime.choices.model}` interpolation, `key=value` / `+key=value` / group overrides, and
+`_target_` instantiation of the drop-in task classes (no GPU needed to construct them)."""
+import textwrap
+
+import pytest
+
+from mrmt3 import hydra_lite
+
+TOP = """
+num_epochs: 800
+devices: 1
+model_type: ${hydra:runtime.choices.model}
+dataset_type: ${hydra:runtime.choices.dataset}
+seed: 365
+path:
+event_length: 1024
+mel_length: 256
+num_rows_per_batch: 12
+model_segmem_length: 4
+optim:
+  lr: 2e-4
+  warmup_steps: 64500
+  num_epochs: ${num_epochs}
+  num_steps_per_epoch: 1289
+  min_lr: 1e-4
+grad_accum: 1
+trainer:
+  precision: 32
+  max_epochs: ${num_epochs}
+  accumulate_grad_batches: ${grad_accum}
+  strategy: "ddp_find_unused_parameters_false"
+  devices: ${devices}
+eval:
+  eval_after_num_epoch: 400
+  batch_size: 8
+defaults:
+  - model: MT3Net
+  - dataset: Slakh
+"""
+
+MODEL = """
+_target_: tasks.%s
+config:
+  architectures:
+    - T5ForConditionalGeneration
+  d_ff: 1024
+  d_kv: 64
+  d_model: 512
+  decoder_start_token_id: 0
+  dropout_rate: 0.1
+  pad_token_id: 0
+  eos_token_id: 1
+  unk_token_id: 2
+  feed_forward_proj: gated-gelu
+  layer_norm_epsilon: 1e-06
+  num_heads: 6
+  num_decoder_layers: 8
+  num_layers: 8
+  tie_word_embeddings: false
+  vocab_size: 1536
+  %s
+  use_cache: False
+"""
+
+
+@pytest.fixture()
+def cfgdir(tmp_path):
+    (tmp_path / "model").mkdir()
+    (tmp_path / "dataset").mkdir()
+    (tmp_path / "config_slakh_segmem.yaml").write_text(TOP)
+    (tmp_path / "model" / "MT3Net.yaml").write_text(MODEL % ("mt3_net.MT3Net", ""))
+    seg = "segmem_num_layers: 1\n  segmem_length: ${model_segmem_length}"
+    (tmp_path / "model" / "MT3NetSegMemV2WithPrev.yaml").write_text(
+        MODEL % ("mt3_net_segmem_v2_with_prev.MT3NetSegMemV2WithPrev", seg))
+    (tmp_path / "dataset" / "Slakh.yaml").write_text("train:\n  mel_length: ${mel_length}\n")
+    return str(tmp_path)
+
+
+def test_compose_interpolation_and_overrides(cfgdir):
+    cfg = hydra_lite.compose(cfgdir, "config_slakh_segmem", ["devices=[0,1]", "optim.lr=1e-5", "+eval.load_weights_strict=False"])
+    assert cfg.model_type == "MT3Net" and cfg.dataset_type == "Slakh"
+    assert cfg.optim.num_epochs == 800 and cfg.trainer.max_epochs == 800 and cfg.trainer.devices == [0, 1]
+    assert cfg.optim.lr == 1e-5 and cfg.eval.load_weights_strict is False
+    assert cfg.dataset.train.mel_length == 256
+    with pytest.raises(KeyError):
+        hydra_lite.compose(cfgdir, "config_slakh_segmem", ["optim.nope=1"])
+
+
+def test_group_override_and_instantiate(cfgdir):
+    cfg = hydra_lite.compose(cfgdir, "config_slakh_segmem", ["model=MT3NetSegMemV2WithPrev", "model_segmem_length=64"])
+    assert cfg.model_type == "MT3NetSegMemV2WithPrev" and cfg.model.config.segmem_length == 64
+    task = hydra_lite.instantiate(cfg.model, optim_cfg=cfg.optim, eval_cfg=cfg.eval)
+    assert type(task).__name__ == cfg.model._target_.split(".")[-1]           # train.py:36
+    assert task.model.segmem_length == 64 and task.model.flat.numel == 48519680
+    (opt,), (sched,) = task.configure_optimizers()
+    assert opt.defaults["lr"] == 2e-4 and sched["interval"] == "step"
+    base = hydra_lite.instantiate(hydra_lite.compose(cfgdir, "config_slakh_segmem").model, optim_cfg=cfg.optim)
+    assert base.model.flat.numel == 45896704 and len(base.model.state_dict()) == 193   # incl. 2 aliases + 2 inv_freq buffers
+
+
+def test_lr_schedule_matches_oracle():
+    from oracle import t5_ref
+    from utils import cosine_warmup_lambda
+    lam = cosine_warmup_lambda(64500, 1289 * 800, min_lr=1e-4)
+    for s in (0, 1, 64499, 64500, 500000, 1031199, 1031200):
+        assert lam(s) == t5_ref.cosine_lambda(s, 64500, 1289 * 800, min_lr=1e-4)
