@@ -38,31 +38,40 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
   return r;
 }
 
-// attention-probability dropout: 16 random bits per (b,h,q,k) element from a counter hash
+// attention-probability dropout.  Element (q,k) of head-matrix bh belongs to the 2x2 group
+// (q>>1, k>>1); one 32-bit mix per group yields four 8-bit lanes, byte ((q&1)<<1 | (k&1)) decides
+// the element.  Every kernel layout (4 consecutive keys per lane in forward/dQ, 4 consecutive
+// queries per lane in dK/dV) therefore needs 2 mixes per 4 elements.  The drop probability is
+// quantised to thresh8/256 (p=0.1 -> 26/256) and the keep scale is 256/(256-thresh8), so forward
+// and backward stay exactly consistent and unbiased.
 struct AttnDrop {
-  unsigned seed_lo, seed_hi;
-  unsigned thresh16;  // p * 65536; 0 = off
+  unsigned seed;
+  unsigned thresh8;  // 0 = off
   float scale;
 };
+#define DROP_CQ 0x9E3779B1u
+#define DROP_CK 0x85EBCA6Bu
+#define DROP_CB 0xC2B2AE35u
 __host__ inline AttnDrop make_attn_drop(float p, unsigned long long seed, unsigned stream) {
   AttnDrop d;
-  d.seed_lo = (unsigned)seed ^ (stream * 0x9E3779B9u);
-  d.seed_hi = (unsigned)(seed >> 32) + stream;
-  if (p <= 0.f) { d.thresh16 = 0; d.scale = 1.f; }
-  else { d.thresh16 = (unsigned)(p * 65536.0f + 0.5f); d.scale = 1.f / (1.f - p); }
+  d.seed = ((unsigned)seed ^ (unsigned)(seed >> 32)) + stream * 0x27D4EB2Fu;
+  if (p <= 0.f) { d.thresh8 = 0; d.scale = 1.f; }
+  else {
+    d.thresh8 = (unsigned)(p * 256.0f + 0.5f);
+    if (d.thresh8 > 255) d.thresh8 = 255;
+    d.scale = 256.0f / (256.0f - (float)d.thresh8);
+  }
   return d;
 }
-__device__ __forceinline__ unsigned hash32(unsigned x) {
-  x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16;
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-// keep-scale of element `idx` (flat (b,h,q,k) index)
-__device__ __forceinline__ float attn_keep(const AttnDrop& d, unsigned long long idx) {
-  const unsigned long long pair = idx >> 1;
-  unsigned h = hash32(((unsigned)pair ^ d.seed_lo) + hash32((unsigned)(pair >> 32) ^ d.seed_hi));
-  const unsigned r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
-  return r >= d.thresh16 ? d.scale : 0.f;
+__device__ __forceinline__ float keep_of(const AttnDrop& d, unsigned h, unsigned shift) {
+  return ((h >> shift) & 0xFFu) >= d.thresh8 ? d.scale : 0.f;
 }
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
 
 struct AttnParams {
   const bf16_t *q, *k, *v, *o, *d_o;
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
   tile_lstore<64>(&lds[0][0][0], tid, kr);
   tile_lstore<64>(&lds[0][1][0], tid, vr);
   __syncthreads();
-  const unsigned long long drop_base = ((unsigned long long)(b * P.H + h)) * P.Lq;
+  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
 
   for (int j = 0; j < n_kv; ++j) {
     const int cur = j & 1, kv0 = j * 64;
@@ -148,6 +157,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
     const unsigned char* lk = &lds[cur][0][0];
     const unsigned char* lv = &lds[cur][1][0];
 
+    // causal: a tile that lies entirely above this wave's 32 query rows contributes nothing
+    const bool wave_active = !(P.causal && kv0 > q0 + wave * 32 + 31);
+    if (wave_active) {
     // S^T = K . Q^T : sT[qt][kt] holds S^T[key = kt*16 + 4g + r][q = fr]
     f32x4 sT[2][4];
 #pragma unroll
@@ -181,28 +193,35 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
         for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sT[qt][kt][r]);
       mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mloc);
+      // running max kept in the exp2 domain (m2 = max * log2 e): p = exp2(s*log2e - m2)
+      const float m_new = fmaxf(m_run[qt], mloc * LOG2E);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __expf(m_run[qt] - m_use);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
       m_run[qt] = m_new;
       float lsum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(sT[qt][kt][r] - m_use);
+          const float p = __builtin_amdgcn_exp2f(fmaf(sT[qt][kt][r], LOG2E, -m_use));
           lsum += p;
           sT[qt][kt][r] = p;
         }
       l_run[qt] = l_run[qt] * alpha + lsum;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oT[qt][dt] *= alpha;
-      if (P.drop.thresh16) {
-        const unsigned long long rowbase = (drop_base + (unsigned long long)qrow[qt]) * P.Lk + kv0;
+      if (P.drop.thresh8) {
+        const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
+        const unsigned sh = (qrow[qt] & 1) << 4;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sT[qt][kt][r] *= attn_keep(P.drop, rowbase + kt * 16 + fg * 4 + r);
+        for (int kt = 0; kt < 4; ++kt) {
+          const unsigned kp = (unsigned)(kv0 + kt * 16 + fg * 4) >> 1;
+          const unsigned h0 = mix32(qb_ + kp * DROP_CK), h1 = mix32(qb_ + (kp + 1) * DROP_CK);
+          sT[qt][kt][0] *= keep_of(P.drop, h0, sh);
+          sT[qt][kt][1] *= keep_of(P.drop, h0, sh + 8);
+          sT[qt][kt][2] *= keep_of(P.drop, h1, sh);
+          sT[qt][kt][3] *= keep_of(P.drop, h1, sh + 8);
+        }
       }
     }
     // O^T += V^T . P^T : k-slot (g, j) of a 32-key step <-> key = 32*ks + 16*(j>>2) + 4g + (j&3)
@@ -219,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
         for (int qt = 0; qt < 2; ++qt) oT[qt][dt] = mfma16(vt, pb[qt], oT[qt][dt]);
       }
     }
+    }  // wave_active
     if (j + 1 < n_kv) {
       tile_lstore<64>(&lds[cur ^ 1][0][0], tid, kr);
       tile_lstore<64>(&lds[cur ^ 1][1][0], tid, vr);
@@ -239,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
       f32x4 v = oT[qt][dt] * inv;
       *(u32x2*)(orow + dt * 16 + fg * 4) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     }
-    if (fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] + __logf(l);
+    if (fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] * LN2 + __logf(l);
   }
 }
 
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
     tile_gload<32>(dob, P.lddo, qb0, P.Lq, tid, dor);
     if (tid < 32) {
       const int q = qb0 + tid;
-      st_l = q < P.Lq ? lse[q] : 0.f;
+      st_l = q < P.Lq ? lse[q] * LOG2E : 0.f;
       st_d = q < P.Lq ? dlt[q] : 0.f;
     }
   };
@@ -312,13 +332,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
   };
   if (nblk > 0) { gload(qstart); lstore(0); }
   __syncthreads();
-  const unsigned long long drop_base = ((unsigned long long)(b * P.H + h)) * P.Lq;
+  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
 
   for (int it = 0; it < nblk; ++it) {
     const int cur = it & 1, qb0 = qstart + it * 32;
     if (it + 1 < nblk) gload(qb0 + 32);
     const unsigned char* lq = &lds[cur][0][0];
     const unsigned char* ldo_ = &lds[cur][1][0];
+    // causal: a query block entirely above this wave's 32 keys contributes nothing to them
+    const bool wave_active = !(P.causal && qb0 + 31 < k0 + wave * 32);
+    if (wave_active) {
+    const bool need_mask = (qb0 + 32 > P.Lq) || (k0 + 128 > P.Lk) || (P.causal && qb0 < k0 + wave * 32 + 31);
     bf16x8 pdB[2], dsB[2];  // per key tile: B operands built from both query tiles
     f32x4 pd[2][2], ds[2][2];  // [qt][nt]
 #pragma unroll
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
       float lrow[4], drow[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        lrow[r] = lstat[cur][0][qt * 16 + fg * 4 + r];
+        lrow[r] = lstat[cur][0][qt * 16 + fg * 4 + r];   // lse * log2(e), pre-scaled at staging
         drow[r] = lstat[cur][1][qt * 16 + fg * 4 + r];
       }
 #pragma unroll
@@ -340,15 +364,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
         s = mfma16(qa1, kf[nt][1], s);
         dp = mfma16(da0, vf[nt][0], dp);
         dp = mfma16(da1, vf[nt][1], dp);
+        float pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lrow[r]));
+        if (need_mask) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qb0 + qt * 16 + fg * 4 + r;
+            const bool valid = q < P.Lq && key[nt] < P.Lk && !(P.causal && key[nt] > q);
+            if (!valid) pv[r] = 0.f;
+          }
+        }
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (P.drop.thresh8) {
+          const unsigned qp = (unsigned)(qb0 + qt * 16 + fg * 4) >> 1;
+          const unsigned kb_ = drop_bh + ((unsigned)key[nt] >> 1) * DROP_CK;
+          const unsigned h0 = mix32(kb_ + qp * DROP_CQ), h1 = mix32(kb_ + (qp + 1) * DROP_CQ);
+          const unsigned sh = (key[nt] & 1) << 3;
+          kp[0] = keep_of(P.drop, h0, sh);
+          kp[1] = keep_of(P.drop, h0, sh + 16);
+          kp[2] = keep_of(P.drop, h1, sh);
+          kp[3] = keep_of(P.drop, h1, sh + 16);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qb0 + qt * 16 + fg * 4 + r;
-          const bool valid = q < P.Lq && key[nt] < P.Lk && !(P.causal && key[nt] > q);
-          float p = valid ? __expf(s[r] - lrow[r]) : 0.f;
-          float keep = 1.f;
-          if (P.drop.thresh16) keep = attn_keep(P.drop, (drop_base + (unsigned long long)q) * P.Lk + key[nt]);
-          pd[qt][nt][r] = p * keep;
-          ds[qt][nt][r] = p * (dp[r] * keep - drow[r]);
+          pd[qt][nt][r] = pv[r] * kp[r];
+          ds[qt][nt][r] = pv[r] * (dp[r] * kp[r] - drow[r]);
         }
       }
     }
@@ -368,6 +409,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
         dkT[nt][dt] = mfma16(qt_, dsB[nt], dkT[nt][dt]);
       }
     }
+    }  // wave_active
     if (it + 1 < nblk) lstore(cur ^ 1);
     __syncthreads();
   }
@@ -410,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
       qf[qt][ks] = *(const bf16x8*)(qb + (size_t)r * P.ldq + ks * 32 + fg * 8);
       dof[qt][ks] = *(const bf16x8*)(dob + (size_t)r * P.lddo + ks * 32 + fg * 8);
     }
-    lse_q[qt] = P.lse[((size_t)b * P.H + h) * P.Lq + r];
+    lse_q[qt] = P.lse[((size_t)b * P.H + h) * P.Lq + r] * LOG2E;
     dlt_q[qt] = P.delta[((size_t)b * P.H + h) * P.Lq + r];
   }
   f32x4 dqT[2][4];
@@ -427,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
   tile_lstore<64>(&lds[0][0][0], tid, kr);
   tile_lstore<64>(&lds[0][1][0], tid, vr);
   __syncthreads();
-  const unsigned long long drop_base = ((unsigned long long)(b * P.H + h)) * P.Lq;
+  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
 
   for (int j = 0; j < n_kv; ++j) {
     const int cur = j & 1, kv0 = j * 64;
@@ -437,6 +479,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
     }
     const unsigned char* lk = &lds[cur][0][0];
     const unsigned char* lv = &lds[cur][1][0];
+    const bool wave_active = !(P.causal && kv0 > q0 + wave * 32 + 31);
+    if (wave_active) {
+    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + wave * 32);
     f32x4 dsT[2][4];  // [qt][kt] : dS^T[key = kt*16+4g+r][q = fr]
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -451,15 +496,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
         s = mfma16(ka1, qf[qt][1], s);
         dp = mfma16(va0, dof[qt][0], dp);
         dp = mfma16(va1, dof[qt][1], dp);
+        float pv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + kt * 16 + fg * 4 + r;
-          const bool valid = key < P.Lk && !(P.causal && key > qrow[qt]);
-          const float p = valid ? __expf(s[r] - lse_q[qt]) : 0.f;
-          float keep = 1.f;
-          if (P.drop.thresh16) keep = attn_keep(P.drop, (drop_base + (unsigned long long)qrow[qt]) * P.Lk + key);
-          dsT[qt][kt][r] = p * (dp[r] * keep - dlt_q[qt]);
+        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lse_q[qt]));
+        if (need_mask) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + kt * 16 + fg * 4 + r;
+            if (key >= P.Lk || (P.causal && key > qrow[qt])) pv[r] = 0.f;
+          }
         }
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (P.drop.thresh8) {
+          const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
+          const unsigned sh = (qrow[qt] & 1) << 4;
+          const unsigned kpi = (unsigned)(kv0 + kt * 16 + fg * 4) >> 1;
+          const unsigned h0 = mix32(qb_ + kpi * DROP_CK), h1 = mix32(qb_ + (kpi + 1) * DROP_CK);
+          kp[0] = keep_of(P.drop, h0, sh);
+          kp[1] = keep_of(P.drop, h0, sh + 8);
+          kp[2] = keep_of(P.drop, h1, sh);
+          kp[3] = keep_of(P.drop, h1, sh + 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsT[qt][kt][r] = pv[r] * (dp[r] * kp[r] - dlt_q[qt]);
       }
     }
 #pragma unroll
@@ -475,6 +534,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
         for (int qt = 0; qt < 2; ++qt) dqT[qt][dt] = mfma16(kt_, db[qt], dqT[qt][dt]);
       }
     }
+    }  // wave_active
     if (j + 1 < n_kv) {
       tile_lstore<64>(&lds[cur ^ 1][0][0], tid, kr);
       tile_lstore<64>(&lds[cur ^ 1][1][0], tid, vr);

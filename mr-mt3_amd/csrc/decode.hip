@@ -49,47 +49,55 @@ __device__ __forceinline__ float gelu_new_d(float x) {
 #define ST_FIN 2
 #define ST_FLAGS 4
 
-// ---- RMS norm of x[b] into LDS (every workgroup recomputes it: 512 floats per row) -----------------
-__device__ __forceinline__ void norm_to_lds(const float* __restrict__ x, const float* __restrict__ lnw, float eps,
-                                            int B, float* xn /*[B][512]*/, float* red /*[4]*/) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int b = 0; b < B; ++b) {
-    const float a0 = x[b * DMODEL + tid], a1 = x[b * DMODEL + 256 + tid];
-    float ss = wave_sum(a0 * a0 + a1 * a1);
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    ss = (red[0] + red[1]) + (red[2] + red[3]);
-    const float rstd = rsqrtf(ss / (float)DMODEL + eps);
-    xn[b * DMODEL + tid] = lnw[tid] * (a0 * rstd);
-    xn[b * DMODEL + 256 + tid] = lnw[256 + tid] * (a1 * rstd);
-    __syncthreads();
-  }
-}
-
+// ---- norm + gemv: every WAVE normalises x[b] for itself from registers (8 elements per lane, one
+// wave_sum per sequence) — no LDS, no workgroup barrier — then streams its weight rows with 16-byte
+// loads, all rows' loads issued before the first dot product.
 // MODE 0: out[b][n] (f32, ld = N)      — cross-attention q, lm_head logits
 // MODE 1: fused q|k|v: n < inner -> q scratch; else K / V cache row t of this layer
 // MODE 2: gated GELU: rows n and n+N of W ([2N][512]) -> out[b][n] = gelu_new(h0) * h1
-template <typename TW, int MODE>
+#define GV_ROWS 2   // weight rows per wave
+template <typename TW, int MODE, int NB>
 __global__ __launch_bounds__(256) void dec_norm_gemv(const float* __restrict__ x, const float* __restrict__ lnw,
-                                                     const TW* __restrict__ W, int N, int B, float eps,
+                                                     const TW* __restrict__ W, int N, float eps,
                                                      float* __restrict__ out, TW* __restrict__ kc, TW* __restrict__ vc,
                                                      int inner, size_t cache_bstride, const int* __restrict__ state) {
-  __shared__ float xn[DEC_MAXB * DMODEL];
-  __shared__ float red[4];
-  norm_to_lds(x, lnw, eps, B, xn, red);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * GV_ROWS;
+  if (n0 >= N) return;
+  // weight rows first (longest latency), then x
+  float w0[GV_ROWS][8], w1[GV_ROWS][8];
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r) {
+    const int n = min(n0 + r, N - 1);
+    load8<TW>(W + (size_t)n * DMODEL + lane * 8, w0[r]);
+    if (MODE == 2) load8<TW>(W + (size_t)(n + N) * DMODEL + lane * 8, w1[r]);
+  }
+  float lw[8];
+  load8<float>(lnw + lane * 8, lw);
+  float xn[NB][8];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    load8<float>(x + b * DMODEL + lane * 8, xn[b]);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf(xn[b][e], xn[b][e], ss);
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)DMODEL + eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xn[b][e] = lw[e] * (xn[b][e] * rstd);
+  }
   const int t = (MODE == 1) ? state[ST_T] : 0;
-  for (int n = (blockIdx.x * 4 + wave) * 2; n < (blockIdx.x * 4 + wave) * 2 + 2 && n < N; ++n) {
-    float w0[8], w1[8];
-    load8<TW>(W + (size_t)n * DMODEL + lane * 8, w0);
-    if (MODE == 2) load8<TW>(W + (size_t)(n + N) * DMODEL + lane * 8, w1);
-    for (int b = 0; b < B; ++b) {
-      const float* xb = xn + b * DMODEL + lane * 8;
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r) {
+    const int n = n0 + r;
+    if (n >= N) break;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s0 = fmaf(w0[e], xb[e], s0);
-        if (MODE == 2) s1 = fmaf(w1[e], xb[e], s1);
+        s0 = fmaf(w0[r][e], xn[b][e], s0);
+        if (MODE == 2) s1 = fmaf(w1[r][e], xn[b][e], s1);
       }
       s0 = wave_sum(s0);
       if (MODE == 2) s1 = wave_sum(s1);
@@ -106,46 +114,64 @@ __global__ __launch_bounds__(256) void dec_norm_gemv(const float* __restrict__ x
   }
 }
 
-// x[b][n] += sum_k a[b][k] * W[n][k]   (O projections and FFN wo, residual add fused)
-template <typename TW>
+// x[b][n] += sum_k a[b][k] * W[n][k]   (O projections and FFN wo, residual add fused); K <= 1024.
+// The activation vector is read straight from L2 into registers (8 per lane per 512-chunk).
+template <typename TW, int NB, int KCH>   // KCH = number of 512-element chunks of K (1 or 2)
 __global__ __launch_bounds__(256) void dec_gemv_res(const float* __restrict__ a, const TW* __restrict__ W,
-                                                    float* __restrict__ x, int N, int K, int B) {
-  extern __shared__ __attribute__((aligned(16))) float as[];  // [B][K]
-  for (int i = threadIdx.x; i < B * K; i += 256) as[i] = a[i];
-  __syncthreads();
+                                                    float* __restrict__ x, int N, int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int n = (blockIdx.x * 4 + wave) * 2; n < (blockIdx.x * 4 + wave) * 2 + 2 && n < N; ++n) {
-    float acc[DEC_MAXB];
+  const int n0 = (blockIdx.x * 4 + wave) * GV_ROWS;
+  if (n0 >= N) return;
+  float w[GV_ROWS][KCH][8];
 #pragma unroll
-    for (int b = 0; b < DEC_MAXB; ++b) acc[b] = 0.f;
-    for (int k0 = lane * 8; k0 < K; k0 += 512) {
-      float w[8];
-      load8<TW>(W + (size_t)n * K + k0, w);
+  for (int r = 0; r < GV_ROWS; ++r)
 #pragma unroll
-      for (int b = 0; b < DEC_MAXB; ++b) {
-        if (b < B) {
-          const float* ab = as + b * K + k0;
+    for (int c = 0; c < KCH; ++c) {
+      const int k0 = c * 512 + lane * 8;
+      if (k0 < K) load8<TW>(W + (size_t)min(n0 + r, N - 1) * K + k0, w[r][c]);
+      else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[b] = fmaf(w[e], ab[e], acc[b]);
-        }
+        for (int e = 0; e < 8; ++e) w[r][c][e] = 0.f;
+      }
+    }
+  float acc[GV_ROWS][NB];
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+      const int k0 = c * 512 + lane * 8;
+      if (k0 < K) {
+        float av[8];
+        load8<float>(a + (size_t)b * K + k0, av);
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[r][b] = fmaf(w[r][c][e], av[e], acc[r][b]);
       }
     }
 #pragma unroll
-    for (int b = 0; b < DEC_MAXB; ++b) {
-      if (b < B) {
-        const float s = wave_sum(acc[b]);
-        if (lane == 0) x[(size_t)b * N + n] += s;
-      }
+  for (int r = 0; r < GV_ROWS; ++r) {
+    if (n0 + r >= N) break;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float s = wave_sum(acc[r][b]);
+      if (lane == 0) x[(size_t)b * N + n0 + r] += s;
     }
   }
 }
 
-// one (head, batch) per workgroup: softmax(q.K^T) V over `len` cached rows (len = t+1 or fixed)
+// one (head, batch) per workgroup: softmax(q.K^T) V over `len` cached rows (len = t+1 or fixed).
+// Scores: one key per thread (8 x 16-byte loads of the key row).  PV: thread = (32 key lanes) x
+// (8 dim-groups of 8): 16-byte V loads, 32 independent partial sums reduced through LDS.
 template <typename TC>
 __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, const TC* __restrict__ kb,
                                                 const TC* __restrict__ vb, int ld, size_t bstride, int fixed_len,
                                                 const int* __restrict__ state, float* __restrict__ o, int inner) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[len] | q[64] | red[8] | part[256]
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[len] | q[64] | red[8] | part[32][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, b = blockIdx.y;
   const int len = fixed_len > 0 ? fixed_len : state[ST_T] + 1;
@@ -160,14 +186,14 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
   float mx = -INFINITY;
   for (int key = tid; key < len; key += 256) {
     const TC* kr = kp + (size_t)key * ld;
+    float kv[8][8];
+#pragma unroll
+    for (int d0 = 0; d0 < 8; ++d0) load8<TC>(kr + d0 * 8, kv[d0]);
     float s = 0.f;
 #pragma unroll
-    for (int d0 = 0; d0 < 64; d0 += 8) {
-      float kv[8];
-      load8<TC>(kr + d0, kv);
+    for (int d0 = 0; d0 < 8; ++d0)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(qs[d0 + e], kv[e], s);
-    }
+      for (int e = 0; e < 8; ++e) s = fmaf(qs[d0 * 8 + e], kv[d0][e], s);
     sc[key] = s;
     mx = fmaxf(mx, s);
   }
@@ -185,11 +211,26 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
   if (lane == 0) red[4 + wave] = se;
   __syncthreads();
   se = (red[4] + red[5]) + (red[6] + red[7]);
-  float acc = 0.f;
-  for (int key = wave; key < len; key += 4) acc = fmaf(sc[key], ldf<TC>(vp + (size_t)key * ld + lane), acc);
-  part[wave * 64 + lane] = acc;
+  const int dg = tid & 7, kl = tid >> 3;   // 8 dims per thread, 32 key lanes
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int key = kl; key < len; key += 32) {
+    float vv[8];
+    load8<TC>(vp + (size_t)key * ld + dg * 8, vv);
+    const float p = sc[key];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vv[e], acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[kl * 64 + dg * 8 + e] = acc[e];
   __syncthreads();
-  if (tid < 64) o[(size_t)b * inner + h * 64 + tid] = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) / se;
+  if (tid < 64) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r += part[k * 64 + tid];
+    o[(size_t)b * inner + h * 64 + tid] = r / se;
+  }
 }
 
 // argmax + EOS bookkeeping (models/t5.py:286-295) + embedding of the next token; single workgroup
@@ -278,7 +319,7 @@ extern "C" int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_mod
   *out = nullptr;
   MR_CHECK_ARG(d_model == DMODEL, "decoder_create: kernels are specialised for d_model = 512");
   MR_CHECK_ARG(n_layers > 0 && n_layers <= 64 && max_batch > 0 && max_batch <= DEC_MAXB, "decoder_create: need 1..64 layers, batch <= 8");
-  MR_CHECK_ARG(d_ff % 8 == 0 && d_ff <= 4096 && vocab > 0 && max_len > 0 && max_enc_len > 0, "decoder_create: bad sizes");
+  MR_CHECK_ARG(d_ff % 8 == 0 && d_ff <= 1024 && n_heads * 64 <= 512 && vocab > 0 && max_len > 0 && max_enc_len > 0, "decoder_create: need d_ff <= 1024, heads*64 <= 512");
   MR_CHECK_ARG(w_dtype == MRMT3_F32 || w_dtype == MRMT3_BF16, "decoder_create: bad dtype");
   mrmt3_decoder* D = new mrmt3_decoder();
   memset(D, 0, sizeof(*D));
@@ -337,40 +378,42 @@ extern "C" int mrmt3_decoder_begin(mrmt3_decoder* D, const mrmt3_decoder_weights
   return MRMT3_OK;
 }
 
-template <typename TW>
+template <typename TW, int NB>
 static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   const int B = D->B, inner = D->inner, dff = D->dff, V = D->V;
   const size_t cache_b = (size_t)D->maxLen * inner;             // elements per batch row of a layer's cache
   const size_t cache_l = (size_t)D->maxB * cache_b;             // elements per layer
-  const size_t attn_shm_self = (size_t)(((D->maxLen + 3) & ~3) + 64 + 8 + 256) * sizeof(float);
-  const size_t attn_shm_cross = (size_t)(((D->encLen + 3) & ~3) + 64 + 8 + 256) * sizeof(float);
+  const size_t attn_extra = (size_t)(64 + 8 + 32 * 64) * sizeof(float);
+  const size_t attn_shm_self = (size_t)((D->maxLen + 3) & ~3) * sizeof(float) + attn_extra;
+  const size_t attn_shm_cross = (size_t)((D->encLen + 3) & ~3) * sizeof(float) + attn_extra;
   const TW* ckv = (const TW*)D->cross_kv;
+  const int rows_per_wg = 4 * GV_ROWS;
   for (int l = 0; l < D->L; ++l) {
     TW* kc = (TW*)D->kc + l * cache_l;
     TW* vc = (TW*)D->vc + l * cache_l;
-    hipLaunchKernelGGL((dec_norm_gemv<TW, 1>), dim3(ceil_div(3 * inner, 8)), dim3(256), 0, s, D->x,
-                       (const float*)D->ln_self[l], (const TW*)D->w_qkv[l], 3 * inner, B, D->eps, D->q, kc, vc, inner,
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 1, NB>), dim3(ceil_div(3 * inner, rows_per_wg)), dim3(256), 0, s, D->x,
+                       (const float*)D->ln_self[l], (const TW*)D->w_qkv[l], 3 * inner, D->eps, D->q, kc, vc, inner,
                        cache_b, D->state);
     hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_self, s, D->q, (const TW*)kc, (const TW*)vc,
                        inner, cache_b, 0, D->state, D->o, inner);
-    hipLaunchKernelGGL((dec_gemv_res<TW>), dim3(ceil_div(DMODEL, 8)), dim3(256), sizeof(float) * B * inner, s, D->o,
-                       (const TW*)D->w_o_self[l], D->x, DMODEL, inner, B);
-    hipLaunchKernelGGL((dec_norm_gemv<TW, 0>), dim3(ceil_div(inner, 8)), dim3(256), 0, s, D->x,
-                       (const float*)D->ln_cross[l], (const TW*)D->w_q_cross[l], inner, B, D->eps, D->q, (TW*)nullptr,
+    hipLaunchKernelGGL((dec_gemv_res<TW, NB, 1>), dim3(ceil_div(DMODEL, rows_per_wg)), dim3(256), 0, s, D->o,
+                       (const TW*)D->w_o_self[l], D->x, DMODEL, inner);
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 0, NB>), dim3(ceil_div(inner, rows_per_wg)), dim3(256), 0, s, D->x,
+                       (const float*)D->ln_cross[l], (const TW*)D->w_q_cross[l], inner, D->eps, D->q, (TW*)nullptr,
                        (TW*)nullptr, inner, (size_t)0, D->state);
     const TW* ck = ckv + (size_t)l * B * D->encLen * 2 * inner;
     hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_cross, s, D->q, ck, ck + inner, 2 * inner,
                        (size_t)D->encLen * 2 * inner, D->encLen, D->state, D->o, inner);
-    hipLaunchKernelGGL((dec_gemv_res<TW>), dim3(ceil_div(DMODEL, 8)), dim3(256), sizeof(float) * B * inner, s, D->o,
-                       (const TW*)D->w_o_cross[l], D->x, DMODEL, inner, B);
-    hipLaunchKernelGGL((dec_norm_gemv<TW, 2>), dim3(ceil_div(dff, 8)), dim3(256), 0, s, D->x, (const float*)D->ln_ff[l],
-                       (const TW*)D->w_wi[l], dff, B, D->eps, D->g, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
-                       D->state);
-    hipLaunchKernelGGL((dec_gemv_res<TW>), dim3(ceil_div(DMODEL, 8)), dim3(256), sizeof(float) * B * dff, s, D->g,
-                       (const TW*)D->w_wo[l], D->x, DMODEL, dff, B);
+    hipLaunchKernelGGL((dec_gemv_res<TW, NB, 1>), dim3(ceil_div(DMODEL, rows_per_wg)), dim3(256), 0, s, D->o,
+                       (const TW*)D->w_o_cross[l], D->x, DMODEL, inner);
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 2, NB>), dim3(ceil_div(dff, rows_per_wg)), dim3(256), 0, s, D->x,
+                       (const float*)D->ln_ff[l], (const TW*)D->w_wi[l], dff, D->eps, D->g, (TW*)nullptr, (TW*)nullptr,
+                       inner, (size_t)0, D->state);
+    hipLaunchKernelGGL((dec_gemv_res<TW, NB, 2>), dim3(ceil_div(DMODEL, rows_per_wg)), dim3(256), 0, s, D->g,
+                       (const TW*)D->w_wo[l], D->x, DMODEL, dff);
   }
-  hipLaunchKernelGGL((dec_norm_gemv<TW, 0>), dim3(ceil_div(V, 8)), dim3(256), 0, s, D->x, D->w.final_ln,
-                     (const TW*)D->w.lm_head, V, B, D->eps, D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
+  hipLaunchKernelGGL((dec_norm_gemv<TW, 0, NB>), dim3(ceil_div(V, rows_per_wg)), dim3(256), 0, s, D->x, D->w.final_ln,
+                     (const TW*)D->w.lm_head, V, D->eps, D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
                      D->state);
   hipLaunchKernelGGL(dec_argmax, dim3(1), dim3(256), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
                      (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad);
@@ -378,8 +421,22 @@ static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   return MRMT3_OK;
 }
 
+template <typename TW>
+static int step_b(mrmt3_decoder* D, hipStream_t s) {
+  switch (D->B) {   // batch is a compile-time constant of the kernels: activations live in registers
+    case 1: return launch_step<TW, 1>(D, s);
+    case 2: return launch_step<TW, 2>(D, s);
+    case 3: return launch_step<TW, 3>(D, s);
+    case 4: return launch_step<TW, 4>(D, s);
+    case 5: return launch_step<TW, 5>(D, s);
+    case 6: return launch_step<TW, 6>(D, s);
+    case 7: return launch_step<TW, 7>(D, s);
+    default: return launch_step<TW, 8>(D, s);
+  }
+}
+
 static int step(mrmt3_decoder* D, hipStream_t s) {
-  return D->wdt == MRMT3_BF16 ? launch_step<bf16_t>(D, s) : launch_step<float>(D, s);
+  return D->wdt == MRMT3_BF16 ? step_b<bf16_t>(D, s) : step_b<float>(D, s);
 }
 
 extern "C" int mrmt3_decoder_run(mrmt3_decoder* D, int n_steps, void* stream) {

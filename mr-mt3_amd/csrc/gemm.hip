@@ -8,15 +8,17 @@
 //
 // NT kernel: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4
 // v_mfma_f32_16x16x32_bf16 tiles), K step = 128 bytes of each row (64 bf16 / 32 f32), operands
-// staged global -> registers -> LDS (issue-early / write-late), double-buffered, one barrier per
-// K step.  LDS rows are 128 B with the 16-B chunk index XOR-ed by (row & 7): ds_read_b128 fragment
-// reads are conflict-free.  Workgroup ids are remapped so the 8 XCDs each walk a contiguous run of
+// staged HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write: the
+// register-staged version was LDS-write bound), double-buffered, one barrier per K step.  LDS rows
+// are 128 B with the 16-B chunk index XOR-ed by (row & 7): the LDS image of a wave-instruction is
+// linear (lane x 16 B), so the swizzle is applied to each lane's SOURCE address and again on the
+// ds_read_b128 fragment reads, which are conflict-free.  Workgroup ids are remapped so the 8 XCDs each walk a contiguous run of
 // (m-tile, n-tile) pairs and an A row-panel stays in one XCD's L2.
 // f32 inputs use v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) on the same LDS image.
 //
 // TN kernel: 128x128 tile of dW per workgroup, 64 token rows per step; operand tiles are stored
-// row-major [64][128] with a 288-B row stride and consumed through ds_read_b64_tr_b16 (hardware
-// transpose) so both MFMA operands get their 8 consecutive reduction indices per lane; the token
+// row-major [64][128] (256-B rows, 32-B units XOR-swizzled by row & 7, again via the glds source
+// address) and consumed through ds_read_b64_tr_b16 (hardware transpose) so both MFMA operands get their 8 consecutive reduction indices per lane; the token
 // range is split over workgroups into f32 slabs that a second kernel sums in a fixed order
 // (bitwise reproducible, no atomics).
 #include "common.h"
@@ -49,48 +51,49 @@ __device__ __forceinline__ f32x4 mfma_step(f32x4 a, f32x4 b, f32x4 c) {
   return c;
 }
 
+// NT main kernel: 256 x 128 output tile, 8 waves (4 x 2), 3 LDS stages (A 32 KiB + B 16 KiB each),
+// two K-steps of global_load_lds in flight across a raw s_barrier (counted vmcnt, never drained in
+// the loop).  A 128^2 tile needs 64 FLOP per L2 byte -> ~39 TB/s of L2->LDS traffic at the MFMA
+// peak, more than the chip has; 256x128 needs 85 FLOP/B and leaves two tiles of latency cover.
+#define NT_BM 256
+#define NT_BN 128
+#define NT_STAGES 3
+#define NT_STAGE_BYTES ((NT_BM + NT_BN) * ROWB)
+
 template <typename TIN, typename TOUT, bool ACCUM>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
                                                          const TIN* __restrict__ B, int ldb,
                                                          TOUT* __restrict__ C, int ldc, int M, int N,
                                                          int K, int tiles_n) {
   constexpr int EPC = 16 / sizeof(TIN);    // elements per 16-B chunk
   constexpr int BK = ROWB / sizeof(TIN);   // elements per K step
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TILE * ROWB];  // [buf][A|B]
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NT_STAGES * NT_STAGE_BYTES];  // 144 KiB, one object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int nwg = gridDim.x;
-  const int t = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (t / tiles_n) * TILE, n0 = (t % tiles_n) * TILE;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  const int wr = uw >> 1, wc = uw & 1;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / tiles_n) * NT_BM, n0 = (t % tiles_n) * NT_BN;
 
-  // staging map: 4 chunks per thread per operand
-  int srow[4], schunk[4];
+  // staging: A tile = 32 wave-instructions of 1 KiB (8 rows x 128 B), B tile = 16; wave w issues A
+  // instructions 4w..4w+3 and B instructions 2w, 2w+1.  Lane p fills LDS chunk (row = 8t + p/8, c' = p%8)
+  // with global chunk c = c' ^ (row & 7) = (p%8) ^ (p/8)  (swizzle applied on the source address).
+  const int srow = lane >> 3, schunk = (lane & 7) ^ (lane >> 3);
   const TIN* ga[4];
-  const TIN* gb[4];
+  const TIN* gb[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int q = tid + 256 * i;
-    srow[i] = q >> 3;
-    schunk[i] = q & 7;
-    int ra = min(m0 + srow[i], M - 1), rb = min(n0 + srow[i], N - 1);
-    ga[i] = A + (size_t)ra * lda + schunk[i] * EPC;
-    gb[i] = B + (size_t)rb * ldb + schunk[i] * EPC;
-  }
-  u32x4 ra_[4], rb_[4];
-  auto gload = [&](int k0) {
+  for (int i = 0; i < 4; ++i) ga[i] = A + (size_t)min(m0 + (uw * 4 + i) * 8 + srow, M - 1) * lda + schunk * EPC;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra_[i] = *(const u32x4*)(ga[i] + k0);
-      rb_[i] = *(const u32x4*)(gb[i] + k0);
-    }
-  };
-  auto lstore = [&](int buf) {
+  for (int i = 0; i < 2; ++i) gb[i] = B + (size_t)min(n0 + (uw * 2 + i) * 8 + srow, N - 1) * ldb + schunk * EPC;
+  auto stage = [&](int buf, int k0) {
+    unsigned char* base = lds + buf * NT_STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int off = srow[i] * ROWB + ((schunk[i] ^ (srow[i] & 7)) << 4);
-      *(u32x4*)(&lds[buf][0][off]) = ra_[i];
-      *(u32x4*)(&lds[buf][1][off]) = rb_[i];
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + (uw * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + NT_BM * ROWB + (uw * 2 + i) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[4][4];
@@ -101,14 +104,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TIN* __restrict__
 
   const int fr = lane & 15, fg = lane >> 4;
   const int nk = K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  stage(0, 0);
+  if (nk > 1) stage(1, BK);
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
-    const unsigned char* la = &lds[cur][0][0];
-    const unsigned char* lb = &lds[cur][1][0];
+    // tile kt has landed once at most the 6 loads of tile kt+1 are still outstanding
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading stage (kt-1)%3
+    if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);   // (kt+2)%3 == (cur+2)%3
+    const unsigned char* la = lds + cur * NT_STAGE_BYTES;
+    const unsigned char* lb = la + NT_BM * ROWB;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       typename Frag<TIN>::type af[4], bfr[4];
@@ -125,29 +131,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TIN* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
-    __syncthreads();
+    cur = cur == NT_STAGES - 1 ? 0 : cur + 1;
   }
 
-  // epilogue: lane holds C[row = ..+fg*4+r][col = ..+fr]
+  // epilogue.  A lane holds C[row = 16i + 4fg + r][col = 16j + fr]: storing from there means 2/4-byte
+  // stores in 32/64-byte pieces, and the store-issue tail then costs more than the whole K loop.
+  // Instead each wave transposes its 64x64 tile through its own slice of the (now idle) staging LDS
+  // and writes whole rows with 16 bytes per lane.
+  __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
+  constexpr int EP_LD = 68;                           // floats per LDS row (64 + 4 pad, 16-B aligned rows)
+  float* wl = (float*)(lds + uw * (64 * EP_LD * 4));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wr * 64 + i * 16 + fg * 4 + r;
-      if (row >= M) continue;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wc * 64 + j * 16 + fr;
-        if (col >= N) continue;
-        float v = acc[i][j][r];
-        TOUT* p = C + (size_t)row * ldc + col;
-        if constexpr (sizeof(TOUT) == 2) {
-          *p = f2bf(v);
-        } else {
-          if (ACCUM) v += *p;
-          *p = v;
-        }
+      for (int r = 0; r < 4; ++r) wl[(i * 16 + fg * 4 + r) * EP_LD + j * 16 + fr] = acc[i][j][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS round trip: in order, no barrier needed
+  const int rbase = m0 + wr * 64, cbase = n0 + wc * 64;
+  if constexpr (sizeof(TOUT) == 2) {
+    // 64 cols = 128 B per row -> 8 lanes per row, 8 rows per instruction
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int lr = it * 8 + (lane >> 3), lc = (lane & 7) * 8;
+      const f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc), b = *(const f32x4*)(wl + lr * EP_LD + lc + 4);
+      const int row = rbase + lr, col = cbase + lc;
+      if (row < M && col + 8 <= N)
+        *(u32x4*)(C + (size_t)row * ldc + col) =
+            u32x4{pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w)};
+    }
+  } else {
+    // 64 cols = 256 B per row -> 16 lanes per row, 4 rows per instruction
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int lr = it * 4 + (lane >> 4), lc = (lane & 15) * 4;
+      f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc);
+      const int row = rbase + lr, col = cbase + lc;
+      if (row < M && col + 4 <= N) {
+        f32x4* p = (f32x4*)(C + (size_t)row * ldc + col);
+        if (ACCUM) a += *p;
+        *p = a;
       }
     }
   }
@@ -156,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const TIN* __restrict__
 template <typename TIN, typename TOUT, bool ACCUM>
 static int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      hipStream_t s) {
-  const int tiles_m = ceil_div(M, TILE), tiles_n = ceil_div(N, TILE);
-  dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
+  const int tiles_m = ceil_div(M, NT_BM), tiles_n = ceil_div(N, NT_BN);
+  dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
   hipLaunchKernelGGL((gemm_nt_kernel<TIN, TOUT, ACCUM>), grid, block, 0, s, (const TIN*)A, lda, (const TIN*)B, ldb,
                      (TOUT*)C, ldc, M, N, K, tiles_n);
   MR_CHECK_LAUNCH("gemm_nt");
@@ -171,6 +194,12 @@ extern "C" int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, voi
   const int esz = in_dtype == MRMT3_BF16 ? 2 : 4;
   MR_CHECK_ARG((K * esz) % ROWB == 0, "gemm_nt: K*elem_size must be a multiple of 128 bytes (K=%d)", K);
   MR_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "gemm_nt: row strides must be 16-byte multiples");
+  {
+    const int osz = out_dtype == MRMT3_BF16 ? 2 : 4;
+    MR_CHECK_ARG((ldc * osz) % 16 == 0 && (N * osz) % 16 == 0 && ((uintptr_t)C % 16) == 0,
+                 "gemm_nt: C rows must be 16-byte aligned (ldc, N multiples of %d)", 16 / osz);
+    MR_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_nt: A and B must be 16-byte aligned");
+  }
   MR_CHECK_ARG(!(accumulate && out_dtype != MRMT3_F32), "gemm_nt: accumulate needs f32 output");
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == MRMT3_BF16) {
@@ -190,7 +219,9 @@ extern "C" int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, voi
 // TN: C[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (bf16 in, f32 out)
 // ------------------------------------------------------------------------------------------------
 #define TN_ROWS 64    // token rows per step
-#define TN_STRIDE 288  // bytes per LDS row: 128 bf16 + 32 B pad (8 consecutive rows -> disjoint banks)
+#define TN_STRIDE 256  // bytes per LDS row (128 bf16); 32-B units XOR-swizzled by (row & 7)
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // source of out-of-range rows
 
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -207,35 +238,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   const int a0 = (tile / tiles_n2) * TILE, b0 = (tile % tiles_n2) * TILE;
   const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
 
-  // staging: tile is 64 rows x 16 chunks(16 B) = 1024 chunks per operand -> 4 per thread
-  int srow[4], schunk[4];
+  // staging: a tile (64 rows x 256 B = 16 KiB) is 16 wave-instructions of 1 KiB (4 rows); wave w issues
+  // 4w..4w+3.  Lane p fills LDS (row = 4t + p/16, c' = p%16) with global 16-B chunk
+  // c = (((c'>>1) ^ (row&7)) << 1) | (c'&1)  (32-B units swizzled by row).
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  int srow[4], scol_a[4], scol_b[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int q = tid + 256 * i;
-    srow[i] = q >> 4;
-    schunk[i] = q & 15;
+    const int t = uw * 4 + i;
+    srow[i] = t * 4 + (lane >> 4);
+    const int cp = lane & 15;
+    const int c = ((((cp >> 1) ^ (srow[i] & 7)) << 1) | (cp & 1));
+    scol_a[i] = min(a0 + c * 8, N1 - 8);
+    scol_b[i] = min(b0 + c * 8, N2 - 8);
   }
-  u32x4 ra_[4], rb_[4];
-  auto gload = [&](int mrow0) {
+  auto stage = [&](int buf, int mrow0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mrow0 + srow[i];
-      const int ca = min(a0 + schunk[i] * 8, N1 - 8), cb = min(b0 + schunk[i] * 8, N2 - 8);
-      if (m < mend) {
-        ra_[i] = *(const u32x4*)(A + (size_t)m * lda + ca);
-        rb_[i] = *(const u32x4*)(B + (size_t)m * ldb + cb);
-      } else {
-        ra_[i] = {0u, 0u, 0u, 0u};
-        rb_[i] = {0u, 0u, 0u, 0u};
-      }
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int off = srow[i] * TN_STRIDE + (schunk[i] << 4);
-      *(u32x4*)(&lds[buf][0][off]) = ra_[i];
-      *(u32x4*)(&lds[buf][1][off]) = rb_[i];
+      const bool ok = m < mend;
+      const void* pa = ok ? (const void*)(A + (size_t)m * lda + scol_a[i]) : (const void*)(g_zero_page + (lane & 15) * 16);
+      const void* pb = ok ? (const void*)(B + (size_t)m * ldb + scol_b[i]) : (const void*)(g_zero_page + (lane & 15) * 16);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                       (__attribute__((address_space(3))) void*)(&lds[buf][0][(uw * 4 + i) * 1024]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb,
+                                       (__attribute__((address_space(3))) void*)(&lds[buf][1][(uw * 4 + i) * 1024]), 16, 0, 0);
     }
   };
 
@@ -249,23 +276,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   // address of row (4g+q) [+16 for the second half of the k-slots], columns 4p..4p+3
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
   const int nsteps = ceil_div(max(mend - mbeg, 0), TN_ROWS);
-  if (nsteps > 0) {
-    gload(mbeg);
-    lstore(0);
-  }
+  if (nsteps > 0) stage(0, mbeg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1;
-    if (st + 1 < nsteps) gload(mbeg + (st + 1) * TN_ROWS);
+    if (st + 1 < nsteps) stage(cur ^ 1, mbeg + (st + 1) * TN_ROWS);
     const unsigned char* la = &lds[cur][0][0];
     const unsigned char* lb = &lds[cur][1][0];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int rbase = ks * 32 + fg * 4 + fq;
       bf16x8 af[4], bfr[4];
+      // element column n = w*64 + i*16 + fp*4 -> chunk c = w*8 + i*2 + (fp>>1); the 32-B unit (c>>1)
+      // is XOR-ed with (row & 7) (rbase and rbase+16 share row & 7)
+      const int rx = rbase & 7, sub = (fp >> 1) * 16 + (fp & 1) * 8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int cola = (wr * 64 + i * 16 + fp * 4) * 2, colb = (wc * 64 + i * 16 + fp * 4) * 2;
+        const int cola = (((wr * 4 + i) ^ rx) << 5) + sub, colb = (((wc * 4 + i) ^ rx) << 5) + sub;
         s16x4 a_lo = lds_tr16(la + rbase * TN_STRIDE + cola);
         s16x4 a_hi = lds_tr16(la + (rbase + 16) * TN_STRIDE + cola);
         s16x4 b_lo = lds_tr16(lb + rbase * TN_STRIDE + colb);
@@ -278,24 +306,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
     }
-    if (st + 1 < nsteps) lstore(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
+  // epilogue: transpose each wave's 64x64 tile through LDS (two 32-row halves) and store whole rows
+  // with 16 bytes per lane (see gemm_nt_kernel).
   float* out = slab + (size_t)split * N1 * N2;
   const int fr = lane & 15;
+  constexpr int EP_LD = 68;
+  __syncthreads();
+  float* wl = (float*)(&lds[0][0][0] + uw * (32 * EP_LD * 4));
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = a0 + wr * 64 + i * 16 + fg * 4 + r;
-      if (row >= N1) continue;
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = b0 + wc * 64 + j * 16 + fr;
-        if (col < N2) out[(size_t)row * N2 + col] = acc[i][j][r];
-      }
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wl[(ii * 16 + fg * 4 + r) * EP_LD + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int lr = it * 4 + (lane >> 4), lc = (lane & 15) * 4;
+      const f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc);
+      const int row = a0 + wr * 64 + half * 32 + lr, col = b0 + wc * 64 + lc;
+      if (row < N1 && col + 4 <= N2) *(f32x4*)(out + (size_t)row * N2 + col) = a;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next half overwrites
+  }
 }
 
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int ldc, int N1, int N2,
