@@ -7,8 +7,9 @@
 //
 // bf16 kernels are flash-style (never materialise [B,H,Lq,Lk]); fp32 softmax statistics.
 //   forward : workgroup = 128 query rows of one (batch, head); 4 waves x 32 rows.  K/V tiles of 64
-//             keys are staged global->regs->LDS (double buffered, 160-B row stride = conflict-free
-//             for both ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads).
+//             keys go HBM->LDS directly (global_load_lds, 3 stages, two tiles in flight across a raw
+//             s_barrier with counted vmcnt); 128-B LDS rows with XOR-swizzled 16-B chunks are
+//             conflict-free for both ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads.
 //             The scores are computed TRANSPOSED (S^T = K.Q^T, query on the MFMA lane) so that the
 //             softmax row statistics are per-lane scalars and the exponentiated tile is already the
 //             B operand of O^T = V^T.P^T (accumulator-as-operand, no LDS round trip for P).
@@ -20,7 +21,6 @@
 #include "common.h"
 
 #define HD 64          // head dim (d_kv)
-#define KV_STRIDE 160  // bytes per LDS row of a [rows][64] bf16 tile
 
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -83,35 +83,38 @@ struct AttnParams {
   AttnDrop drop;
 };
 
-// stage a [ROWS][64] bf16 tile (row-major, KV_STRIDE) : thread handles chunk ids tid, tid+256, ...
-template <int ROWS>
-__device__ __forceinline__ void tile_gload(const bf16_t* base, int ld, int row0, int nrows_valid, int tid, u32x4* regs) {
-#pragma unroll
-  for (int i = 0; i < (ROWS * 8 + 255) / 256; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3, ch = c & 7;
-    if (ROWS * 8 >= 256 || c < ROWS * 8) {
-      if (row0 + row < nrows_valid) regs[i] = *(const u32x4*)(base + (size_t)(row0 + row) * ld + ch * 8);
-      else regs[i] = u32x4{0u, 0u, 0u, 0u};
-    }
-  }
+// ---- LDS tiles: [rows][64] bf16 = 128-B rows, the 16-B chunk index XOR-ed with (row & 7).  Tiles are
+// filled by global_load_lds_dwordx4 (HBM -> LDS, no VGPR round trip): one wave-instruction covers 8
+// rows x 128 B linearly, so the swizzle is applied to each lane's SOURCE chunk.  The same image
+// serves ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads, both conflict-free.
+// Rows past the end of the tensor are clamped to the last valid row (their scores are masked).
+__device__ __forceinline__ void glds_rows8(const bf16_t* base, int ld, int row0, int nrows_valid, unsigned char* dst,
+                                           int lane) {
+  const int r = min(row0 + (lane >> 3), nrows_valid - 1);
+  const int c = (lane & 7) ^ (lane >> 3);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)r * ld + c * 8),
+                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
-template <int ROWS>
-__device__ __forceinline__ void tile_lstore(unsigned char* lds, int tid, const u32x4* regs) {
-#pragma unroll
-  for (int i = 0; i < (ROWS * 8 + 255) / 256; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3, ch = c & 7;
-    if (ROWS * 8 >= 256 || c < ROWS * 8) *(u32x4*)(lds + row * KV_STRIDE + ch * 16) = regs[i];
-  }
+__device__ __forceinline__ bf16x8 lds_row8(const unsigned char* tile, int row, int c) {
+  return *(const bf16x8*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
 }
+// transposed fragment: rows {row..row+3 via the lane's fq} and +16, chunk c, 8-byte half `sub`
+__device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* tile, int row, int c, int sub) {
+  const unsigned char* a = tile + row * 128 + ((c ^ (row & 7)) << 4) + sub;
+  return cat8(lds_tr16(a), lds_tr16(a + 16 * 128));
+}
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * KV_STRIDE];  // [buf][K|V]
+#define KV_STAGES 3
+#define KV_STAGE_BYTES 16384   // K tile 8 KiB + V tile 8 KiB
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
   int qrow[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    qrow[qt] = q0 + wave * 32 + qt * 16 + fr;
+    qrow[qt] = q0 + uw * 32 + qt * 16 + fr;
     const int r = min(qrow[qt], P.Lq - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *(const bf16x8*)(qb + (size_t)r * P.ldq + ks * 32 + fg * 8);
@@ -140,32 +143,45 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
 
   int n_kv = ceil_div(P.Lk, 64);
   if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
-  u32x4 kr[2], vr[2];
-  tile_gload<64>(kb, P.ldk, 0, P.Lk, tid, kr);
-  tile_gload<64>(vb, P.ldv, 0, P.Lk, tid, vr);
-  tile_lstore<64>(&lds[0][0][0], tid, kr);
-  tile_lstore<64>(&lds[0][1][0], tid, vr);
-  __syncthreads();
+  // each wave stages 16 rows of K and of V per tile (2 + 2 wave-instructions)
+  auto stage = [&](int buf, int kv0) {
+    unsigned char* base = lds + buf * KV_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = uw * 2 + i;
+      glds_rows8(kb, P.ldk, kv0 + t * 8, P.Lk, base + t * 1024, lane);
+      glds_rows8(vb, P.ldv, kv0 + t * 8, P.Lk, base + 8192 + t * 1024, lane);
+    }
+  };
+  stage(0, 0);
+  if (n_kv > 1) stage(1, 64);
   const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  int cur = 0;
 
   for (int j = 0; j < n_kv; ++j) {
-    const int cur = j & 1, kv0 = j * 64;
-    if (j + 1 < n_kv) {
-      tile_gload<64>(kb, P.ldk, kv0 + 64, P.Lk, tid, kr);
-      tile_gload<64>(vb, P.ldv, kv0 + 64, P.Lk, tid, vr);
-    }
-    const unsigned char* lk = &lds[cur][0][0];
-    const unsigned char* lv = &lds[cur][1][0];
+    const int kv0 = j * 64;
+#ifndef ATTN_E3
+    if (j + 1 < n_kv) VMCNT(4); else VMCNT(0);      // tile j landed (tile j+1 may still be in flight)
+    __builtin_amdgcn_s_barrier();
+#endif
+#ifndef ATTN_E2
+    if (j + 2 < n_kv) stage(cur == 0 ? 2 : cur - 1, kv0 + 128);
+#endif
+    const unsigned char* lk = lds + cur * KV_STAGE_BYTES;
+    const unsigned char* lv = lk + 8192;
+#ifndef ATTN_E2
+    cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
+#endif
 
     // causal: a tile that lies entirely above this wave's 32 query rows contributes nothing
-    const bool wave_active = !(P.causal && kv0 > q0 + wave * 32 + 31);
+    const bool wave_active = !(P.causal && kv0 > q0 + uw * 32 + 31);
     if (wave_active) {
     // S^T = K . Q^T : sT[qt][kt] holds S^T[key = kt*16 + 4g + r][q = fr]
     f32x4 sT[2][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      bf16x8 ka0 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + (fg) * 16);
-      bf16x8 ka1 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+      bf16x8 ka0 = lds_row8(lk, kt * 16 + fr, fg);
+      bf16x8 ka1 = lds_row8(lk, kt * 16 + fr, 4 + fg);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
         sT[qt][kt] = acc;
       }
     }
-    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + wave * 32);
+    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * 32);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       if (need_mask) {
@@ -203,7 +219,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#ifdef ATTN_E1
+          const float p = sT[qt][kt][r] * 1e-3f;
+#else
           const float p = __builtin_amdgcn_exp2f(fmaf(sT[qt][kt][r], LOG2E, -m_use));
+#endif
           lsum += p;
           sT[qt][kt][r] = p;
         }
@@ -232,18 +252,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnParams P) {
       for (int qt = 0; qt < 2; ++qt) pb[qt] = pack8(sT[qt][2 * ks], sT[qt][2 * ks + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const unsigned char* a = lv + (ks * 32 + fg * 4 + fq) * KV_STRIDE + (dt * 16 + fp * 4) * 2;
-        bf16x8 vt = cat8(lds_tr16(a), lds_tr16(a + 16 * KV_STRIDE));
+        bf16x8 vt = lds_tr8(lv, ks * 32 + fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) oT[qt][dt] = mfma16(vt, pb[qt], oT[qt][dt]);
       }
     }
     }  // wave_active
-    if (j + 1 < n_kv) {
-      tile_lstore<64>(&lds[cur ^ 1][0][0], tid, kr);
-      tile_lstore<64>(&lds[cur ^ 1][1][0], tid, vr);
-    }
-    __syncthreads();
   }
 
 #pragma unroll
@@ -279,12 +293,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: dK, dV.  workgroup = 128 keys (wave = 32 keys, key on the lane), loop over 32-query blocks
+// backward: dK, dV.  workgroup = 128 keys (wave = 32 keys, key on the lane), loop over 32-query
+// blocks staged 3 blocks ahead (4 LDS stages of Q | dO | lse,delta)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][32 * KV_STRIDE];  // [buf][Q|dO]
-  __shared__ float lstat[2][2][32];                                                  // [buf][lse|delta]
+#define QD_STAGES 4
+#define QD_STAGE_BYTES 8448   // Q 4 KiB + dO 4 KiB + 64 floats
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[QD_STAGES * QD_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   const int k0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
   int key[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    key[nt] = k0 + wave * 32 + nt * 16 + fr;
+    key[nt] = k0 + uw * 32 + nt * 16 + fr;
     const int r = min(key[nt], P.Lk - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -314,48 +332,47 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
 
   const int qstart = P.causal ? (k0 / 32) * 32 : 0;
   const int nblk = qstart < P.Lq ? ceil_div(P.Lq - qstart, 32) : 0;
-  u32x4 qr[1], dor[1];
-  float st_l = 0.f, st_d = 0.f;
-  auto gload = [&](int qb0) {
-    tile_gload<32>(qb, P.ldq, qb0, P.Lq, tid, qr);
-    tile_gload<32>(dob, P.lddo, qb0, P.Lq, tid, dor);
-    if (tid < 32) {
-      const int q = qb0 + tid;
-      st_l = q < P.Lq ? lse[q] * LOG2E : 0.f;
-      st_d = q < P.Lq ? dlt[q] : 0.f;
-    }
+  // per tile every wave issues: 8 rows of Q, 8 rows of dO, and the 64 row statistics (the same
+  // 256 bytes from all four waves — identical data, keeps the vmcnt arithmetic uniform)
+  auto stage = [&](int buf, int qb0) {
+    unsigned char* base = lds + buf * QD_STAGE_BYTES;
+    glds_rows8(qb, P.ldq, qb0 + uw * 8, P.Lq, base + uw * 1024, lane);
+    glds_rows8(dob, P.lddo, qb0 + uw * 8, P.Lq, base + 4096 + uw * 1024, lane);
+    const float* sp = (lane < 32 ? lse : dlt) + min(qb0 + (lane & 31), P.Lq - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                     (__attribute__((address_space(3))) void*)(base + 8192), 4, 0, 0);
   };
-  auto lstore = [&](int buf) {
-    tile_lstore<32>(&lds[buf][0][0], tid, qr);
-    tile_lstore<32>(&lds[buf][1][0], tid, dor);
-    if (tid < 32) { lstat[buf][0][tid] = st_l; lstat[buf][1][tid] = st_d; }
-  };
-  if (nblk > 0) { gload(qstart); lstore(0); }
-  __syncthreads();
+  for (int i = 0; i < 3 && i < nblk; ++i) stage(i, qstart + i * 32);
   const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  int cur = 0;
 
   for (int it = 0; it < nblk; ++it) {
-    const int cur = it & 1, qb0 = qstart + it * 32;
-    if (it + 1 < nblk) gload(qb0 + 32);
-    const unsigned char* lq = &lds[cur][0][0];
-    const unsigned char* ldo_ = &lds[cur][1][0];
+    const int qb0 = qstart + it * 32;
+    const int ahead = min(2, nblk - 1 - it);   // tiles that may stay in flight (3 loads each)
+    if (ahead == 2) VMCNT(6); else if (ahead == 1) VMCNT(3); else VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (it + 3 < nblk) stage(cur == 0 ? 3 : cur - 1, qb0 + 96);
+    const unsigned char* lq = lds + cur * QD_STAGE_BYTES;
+    const unsigned char* ldo_ = lq + 4096;
+    const float* lstat = (const float*)(lq + 8192);   // [0..31] lse, [32..63] delta
+    cur = cur == QD_STAGES - 1 ? 0 : cur + 1;
     // causal: a query block entirely above this wave's 32 keys contributes nothing to them
-    const bool wave_active = !(P.causal && qb0 + 31 < k0 + wave * 32);
+    const bool wave_active = !(P.causal && qb0 + 31 < k0 + uw * 32);
     if (wave_active) {
-    const bool need_mask = (qb0 + 32 > P.Lq) || (k0 + 128 > P.Lk) || (P.causal && qb0 < k0 + wave * 32 + 31);
+    const bool need_mask = (qb0 + 32 > P.Lq) || (k0 + 128 > P.Lk) || (P.causal && qb0 < k0 + uw * 32 + 31);
     bf16x8 pdB[2], dsB[2];  // per key tile: B operands built from both query tiles
     f32x4 pd[2][2], ds[2][2];  // [qt][nt]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      bf16x8 qa0 = *(const bf16x8*)(lq + (qt * 16 + fr) * KV_STRIDE + fg * 16);
-      bf16x8 qa1 = *(const bf16x8*)(lq + (qt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
-      bf16x8 da0 = *(const bf16x8*)(ldo_ + (qt * 16 + fr) * KV_STRIDE + fg * 16);
-      bf16x8 da1 = *(const bf16x8*)(ldo_ + (qt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+      bf16x8 qa0 = lds_row8(lq, qt * 16 + fr, fg);
+      bf16x8 qa1 = lds_row8(lq, qt * 16 + fr, 4 + fg);
+      bf16x8 da0 = lds_row8(ldo_, qt * 16 + fr, fg);
+      bf16x8 da1 = lds_row8(ldo_, qt * 16 + fr, 4 + fg);
       float lrow[4], drow[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        lrow[r] = lstat[cur][0][qt * 16 + fg * 4 + r];   // lse * log2(e), pre-scaled at staging
-        drow[r] = lstat[cur][1][qt * 16 + fg * 4 + r];
+        lrow[r] = lstat[qt * 16 + fg * 4 + r] * LOG2E;
+        drow[r] = lstat[32 + qt * 16 + fg * 4 + r];
       }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -400,9 +417,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const int off = (fg * 4 + fq) * KV_STRIDE + (dt * 16 + fp * 4) * 2;
-      bf16x8 dot_ = cat8(lds_tr16(ldo_ + off), lds_tr16(ldo_ + off + 16 * KV_STRIDE));
-      bf16x8 qt_ = cat8(lds_tr16(lq + off), lds_tr16(lq + off + 16 * KV_STRIDE));
+      bf16x8 dot_ = lds_tr8(ldo_, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
+      bf16x8 qt_ = lds_tr8(lq, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         dvT[nt][dt] = mfma16(dot_, pdB[nt], dvT[nt][dt]);
@@ -410,8 +426,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
       }
     }
     }  // wave_active
-    if (it + 1 < nblk) lstore(cur ^ 1);
-    __syncthreads();
   }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -430,9 +444,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams P) {
 // ------------------------------------------------------------------------------------------------
 // backward: dQ.  workgroup = 128 queries (wave = 32, query on the lane), loop over 64-key tiles
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * KV_STRIDE];  // [buf][K|V]
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
@@ -445,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
   float lse_q[2], dlt_q[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    qrow[qt] = q0 + wave * 32 + qt * 16 + fr;
+    qrow[qt] = q0 + uw * 32 + qt * 16 + fr;
     const int r = min(qrow[qt], P.Lq - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -463,32 +478,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
 
   int n_kv = ceil_div(P.Lk, 64);
   if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
-  u32x4 kr[2], vr[2];
-  tile_gload<64>(kb, P.ldk, 0, P.Lk, tid, kr);
-  tile_gload<64>(vb, P.ldv, 0, P.Lk, tid, vr);
-  tile_lstore<64>(&lds[0][0][0], tid, kr);
-  tile_lstore<64>(&lds[0][1][0], tid, vr);
-  __syncthreads();
+  auto stage = [&](int buf, int kv0) {
+    unsigned char* base = lds + buf * KV_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = uw * 2 + i;
+      glds_rows8(kb, P.ldk, kv0 + t * 8, P.Lk, base + t * 1024, lane);
+      glds_rows8(vb, P.ldv, kv0 + t * 8, P.Lk, base + 8192 + t * 1024, lane);
+    }
+  };
+  stage(0, 0);
+  if (n_kv > 1) stage(1, 64);
   const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  int cur = 0;
 
   for (int j = 0; j < n_kv; ++j) {
-    const int cur = j & 1, kv0 = j * 64;
-    if (j + 1 < n_kv) {
-      tile_gload<64>(kb, P.ldk, kv0 + 64, P.Lk, tid, kr);
-      tile_gload<64>(vb, P.ldv, kv0 + 64, P.Lk, tid, vr);
-    }
-    const unsigned char* lk = &lds[cur][0][0];
-    const unsigned char* lv = &lds[cur][1][0];
-    const bool wave_active = !(P.causal && kv0 > q0 + wave * 32 + 31);
+    const int kv0 = j * 64;
+    if (j + 1 < n_kv) VMCNT(4); else VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (j + 2 < n_kv) stage(cur == 0 ? 2 : cur - 1, kv0 + 128);
+    const unsigned char* lk = lds + cur * KV_STAGE_BYTES;
+    const unsigned char* lv = lk + 8192;
+    cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
+    const bool wave_active = !(P.causal && kv0 > q0 + uw * 32 + 31);
     if (wave_active) {
-    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + wave * 32);
+    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * 32);
     f32x4 dsT[2][4];  // [qt][kt] : dS^T[key = kt*16+4g+r][q = fr]
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      bf16x8 ka0 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + fg * 16);
-      bf16x8 ka1 = *(const bf16x8*)(lk + (kt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
-      bf16x8 va0 = *(const bf16x8*)(lv + (kt * 16 + fr) * KV_STRIDE + fg * 16);
-      bf16x8 va1 = *(const bf16x8*)(lv + (kt * 16 + fr) * KV_STRIDE + (4 + fg) * 16);
+      bf16x8 ka0 = lds_row8(lk, kt * 16 + fr, fg);
+      bf16x8 ka1 = lds_row8(lk, kt * 16 + fr, 4 + fg);
+      bf16x8 va0 = lds_row8(lv, kt * 16 + fr, fg);
+      bf16x8 va1 = lds_row8(lv, kt * 16 + fr, 4 + fg);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -528,18 +549,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams P) {
       for (int qt = 0; qt < 2; ++qt) db[qt] = pack8(dsT[qt][2 * ks], dsT[qt][2 * ks + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const unsigned char* a = lk + (ks * 32 + fg * 4 + fq) * KV_STRIDE + (dt * 16 + fp * 4) * 2;
-        bf16x8 kt_ = cat8(lds_tr16(a), lds_tr16(a + 16 * KV_STRIDE));
+        bf16x8 kt_ = lds_tr8(lk, ks * 32 + fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) dqT[qt][dt] = mfma16(kt_, db[qt], dqT[qt][dt]);
       }
     }
     }  // wave_active
-    if (j + 1 < n_kv) {
-      tile_lstore<64>(&lds[cur ^ 1][0][0], tid, kr);
-      tile_lstore<64>(&lds[cur ^ 1][1][0], tid, vr);
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
