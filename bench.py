@@ -165,6 +165,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
+    host_issue = time.perf_counter() - t0          # host time to enqueue the steps (device still running)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -184,6 +185,7 @@ def main():
                    "segments_per_gpu": B, "global_segments": B * world, "parallelism": "dp%d" % world,
                    "audio_seconds_per_step": B * world * SEG_SECONDS},
         "final_loss": final_loss,
+        "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
     }
     if rank == 0 and not args.no_roofline:

@@ -80,11 +80,11 @@ int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const flo
                           float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
                           int out_drop, void* stream);
 /* backward of the above:
- *   g    = dxn (f32) [* out-dropout mask]
+ *   g    = dxn (f32 or bf16, dxn_dtype) [* out-dropout mask]
  *   dx1  = dres (nullable) + rmsnorm_bwd(g; x1, rstd, w)          -> dx1 (f32; may alias dres)
  *   dy   = dropmask_y(dx1) as bf16 (nullable)                      -> dy
  *   dw  += sum_rows g * x1 * rstd                                  (f32 atomics into dw[cols]) */
-int mrmt3_add_rmsnorm_bwd(const float* dxn, const float* dres, const float* x1, const float* rstd,
+int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float* dres, const float* x1, const float* rstd,
                           const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
                           float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
                           int out_drop, void* stream);
@@ -161,6 +161,11 @@ int mrmt3_adamw_step(float* p, const float* g, float* m, float* v, size_t n, con
 int mrmt3_transpose(const void* in, int in_dtype, void* out, int out_dtype, int rows, int cols,
                     void* stream);
 int mrmt3_cast(const void* in, int in_dtype, void* out, int out_dtype, size_t n, void* stream);
+/* One launch transposes n_mats bf16 matrices living in two flat buffers.  desc_table: device array of
+ * {int64 src_off, int64 dst_off, int32 rows, int32 cols} (element offsets; dst is [cols][rows]);
+ * tile_start: device int32 prefix sums of ceil(rows/32)*ceil(cols/32), length n_mats. */
+int mrmt3_transpose_batched(const void* src_bf16, void* dst_bf16, const void* desc_table,
+                            const int* tile_start, int n_mats, int total_tiles, void* stream);
 
 /* ---- K12: greedy decode with a KV cache, one hipGraph replay per token -------------------------
  * models/t5.py:251-302 (batched, MT3Net) and models/t5_segmem_v2_with_prev.py:273-291 (B=1 per

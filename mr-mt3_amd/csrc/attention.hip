@@ -281,14 +281,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 // backward: delta = rowsum(dO * O) per (b, h, q)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams P) {
+  // one wave per (b, q) row; lane l covers 8 consecutive columns (16-byte loads), so a head's 64
+  // columns live in 8 consecutive lanes and reduce with three shuffles
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*Lq + q
   if (row >= (size_t)P.B * P.Lq) return;
   const int b = (int)(row / P.Lq), q = (int)(row % P.Lq);
-  for (int h = 0; h < P.H; ++h) {
-    float a = bf2f(P.d_o[row * P.lddo + h * HD + lane]) * bf2f(P.o[row * P.ldo + h * HD + lane]);
-    a = wave_sum(a);
-    if (lane == 0) P.delta[((size_t)b * P.H + h) * P.Lq + q] = a;
+  const int ncol = P.H * HD;
+  for (int c0 = 0; c0 < ncol; c0 += 512) {
+    const int col = c0 + lane * 8;
+    float a = 0.f;
+    if (col < ncol) {
+      const u32x4 x = *(const u32x4*)(P.d_o + row * P.lddo + col), y = *(const u32x4*)(P.o + row * P.ldo + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a = fmaf(__uint_as_float(x[e] << 16), __uint_as_float(y[e] << 16), a);
+        a = fmaf(__uint_as_float(x[e] & 0xFFFF0000u), __uint_as_float(y[e] & 0xFFFF0000u), a);
+      }
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if ((lane & 7) == 0 && col < ncol) P.delta[((size_t)b * P.H + (col >> 6)) * P.Lq + q] = a;
   }
 }
 
@@ -660,8 +674,8 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
                               float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_bwd: bad sizes");
-  MR_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
-                   lddv % 4 == 0, "attn_bwd: strides must be multiples of 8 (inputs) / 4 (outputs)");
+  MR_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 &&
+                   lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: strides must be multiples of 8 (inputs) / 4 (outputs)");
   AttnParams P;
   memset(&P, 0, sizeof(P));
   P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.o = (const bf16_t*)o;

@@ -234,7 +234,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TN_ROWS * TN_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tile = blockIdx.x % n_tiles, split = blockIdx.x / n_tiles;
+  // XCD-aware order: all output tiles of one token-range (split) run on the same XCD at the same time,
+  // so the 128-row slices of dY and X they share are served by that XCD's L2 instead of being fetched
+  // by all eight.  (blocks with equal blockIdx%8 share an XCD; speed-only assumption.)
+  int tile, split;
+  {
+    const int nsplit = gridDim.x / n_tiles;
+    if ((nsplit & 7) == 0) {
+      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      tile = slot % n_tiles;
+      split = xcd + 8 * (slot / n_tiles);
+    } else {
+      tile = blockIdx.x % n_tiles;
+      split = blockIdx.x / n_tiles;
+    }
+  }
   const int a0 = (tile / tiles_n2) * TILE, b0 = (tile % tiles_n2) * TILE;
   const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
 
@@ -354,12 +368,17 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
 static void tn_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per_split) {
   const int t = ceil_div(N1, TILE) * ceil_div(N2, TILE);
   const int steps = ceil_div(M, TN_ROWS);
-  int s = ceil_div(1024, t);              // aim for ~4 workgroups per CU
+  int s = ceil_div(768, t);               // aim for ~3 workgroups per CU (each split costs a slab round trip)
   s = s < 1 ? 1 : s;
   const int max_s = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps (512 rows) per split
   if (s > max_s) s = max_s;
+  if (s > 8) s = (s + 7) & ~7;            // multiple of 8 -> one XCD per token range (see kernel)
+  if (s > max_s) s = max_s >= 8 ? (max_s & ~7) : max_s;
   int rps = ceil_div(steps, s) * TN_ROWS;
-  s = ceil_div(M, rps);
+  if (ceil_div(M, rps) != s) {            // keep the split count exact (and a multiple of 8 when it was)
+    const int s2 = ceil_div(M, rps);
+    s = s2;
+  }
   *tiles = t; *splits = s; *rows_per_split = rps;
 }
 

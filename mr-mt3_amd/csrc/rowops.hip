@@ -121,8 +121,8 @@ extern "C" int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype
 // backward: each workgroup owns NB_ROWS consecutive rows (wave w takes rows w, w+4, ...), keeps the
 // per-column dw partial sums in registers and issues one f32 atomic per column at the end.
 #define NB_ROWS 32
-template <int NV>
-__global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ dres,
+template <int NV, typename TG>
+__global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restrict__ dxn, const float* __restrict__ dres,
                                                               const float* __restrict__ x1, const float* __restrict__ rstd_in,
                                                               const float* __restrict__ w, float* __restrict__ dx1,
                                                               bf16_t* __restrict__ dy, float* __restrict__ dw, int rows,
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const float* __res
     for (int i = 0; i < NV; ++i) {
       if (i < nv) {
         const int col = i * 256 + lane * 4;
-        load4<float>(dxn + base + col, g[i]);
+        load4<TG>(dxn + base + col, g[i]);
         if (out_drop && dout.thresh) {
           float m[4];
           drop_mask4(dout, (base + col) >> 2, m);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const float* __res
     }
 }
 
-extern "C" int mrmt3_add_rmsnorm_bwd(const float* dxn, const float* dres, const float* x1, const float* rstd,
+extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float* dres, const float* x1, const float* rstd,
                                      const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
                                      float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
                                      int out_drop, void* stream) {
@@ -216,15 +216,21 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const float* dxn, const float* dres, const 
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
   DropCfg dy = make_drop(p_drop, seed, stream_y), dn = make_drop(p_drop, seed, stream_out);
-#define LAUNCH(NV)                                                                                             \
-  hipLaunchKernelGGL(add_rmsnorm_bwd_kernel<NV>, dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0,        \
-                     (hipStream_t)stream, dxn, dres, x1, rstd, w, dx1, (bf16_t*)dy_bf16, dw, rows, cols, dy, dn, \
-                     out_drop)
+#define LAUNCH2(NV, TG)                                                                                           \
+  hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG>), dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0,        \
+                     (hipStream_t)stream, (const TG*)dxn, dres, x1, rstd, w, dx1, (bf16_t*)dy_bf16, dw, rows, cols,   \
+                     dy, dn, out_drop)
+#define LAUNCH(NV)                                       \
+  do {                                                   \
+    if (dxn_dtype == MRMT3_BF16) LAUNCH2(NV, bf16_t);    \
+    else LAUNCH2(NV, float);                             \
+  } while (0)
   if (cols == 512) LAUNCH(2);
   else if (cols == 256) LAUNCH(1);
   else if (cols == 1024) LAUNCH(4);
   else LAUNCH(8);
 #undef LAUNCH
+#undef LAUNCH2
   MR_CHECK_LAUNCH("add_rmsnorm_bwd");
   return MRMT3_OK;
 }
@@ -681,6 +687,40 @@ __global__ void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out
       else out[(size_t)c * rows + r] = v;
     }
   }
+}
+
+// batched bf16 transpose of many small matrices described by a device table of
+// {src_off, dst_off, rows, cols} (element offsets) — one launch refreshes every pre-transposed weight.
+struct TrDesc { long long src, dst; int rows, cols; };
+__global__ void transpose_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                         const TrDesc* __restrict__ tab, const int* __restrict__ tile_start, int n_mats) {
+  __shared__ bf16_t tile[32][33];
+  // find the matrix this block belongs to (tile_start is a prefix sum of 32x32 tile counts)
+  int m = 0;
+  while (m + 1 < n_mats && (int)blockIdx.x >= tile_start[m + 1]) ++m;
+  const TrDesc d = tab[m];
+  const int local = blockIdx.x - tile_start[m];
+  const int tiles_x = (d.cols + 31) / 32;
+  const int bx = (local % tiles_x) * 32, by = (local / tiles_x) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < d.rows && c < d.cols) ? src[d.src + (size_t)r * d.cols + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (r < d.rows && c < d.cols) dst[d.dst + (size_t)c * d.rows + r] = tile[tx][j];
+  }
+}
+
+extern "C" int mrmt3_transpose_batched(const void* src_bf16, void* dst_bf16, const void* desc_table,
+                                       const int* tile_start, int n_mats, int total_tiles, void* stream) {
+  MR_CHECK_ARG(src_bf16 && dst_bf16 && desc_table && tile_start && n_mats > 0 && total_tiles > 0, "transpose_batched: bad args");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src_bf16, (bf16_t*)dst_bf16, (const TrDesc*)desc_table, tile_start, n_mats);
+  MR_CHECK_LAUNCH("transpose_batched");
+  return MRMT3_OK;
 }
 
 extern "C" int mrmt3_transpose(const void* in, int in_dtype, void* out, int out_dtype, int rows, int cols,

@@ -49,7 +49,9 @@ class Engine:
         self._pos = None
         self._stream_ctr = 0
         self.seed = 365
-        self.y_dtype = torch.float32   # dtype of sublayer outputs entering the residual add
+        # dtype of sublayer outputs / dgrad outputs entering the fp32 residual add: the compute dtype
+        # (bf16 halves that stream's HBM traffic; the residual itself and all statistics stay fp32)
+        self.y_dtype = compute_dtype
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def pos(self, device):
@@ -155,7 +157,7 @@ class Engine:
             dg = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.wo"))
             dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, stream_id=t["s_g"])
             lib.gemm_tn(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"), accumulate=True)
-            dxn = lib.gemm_nt(dh, f.WT(f"{prefix}.{i}.wi"), out_dtype=torch.float32)
+            dxn = lib.gemm_nt(dh, f.WT(f"{prefix}.{i}.wi"), out_dtype=self.y_dtype)
             dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
                                          f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
                                          dx1=dx)
@@ -172,7 +174,7 @@ class Engine:
                 lib.gemm_tn(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"), accumulate=True)
                 lib.gemm_tn(dkv, enc, f.GW(f"{prefix}.{i}.ckv"), accumulate=True)
                 lib.gemm_nt(dkv, f.WT(f"{prefix}.{i}.ckv"), out=d_enc, accumulate=True)
-                dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=torch.float32)
+                dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
                 dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
                                              f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
                                              dx1=dx)
@@ -186,7 +188,7 @@ class Engine:
                          dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, H, L, L, is_dec, p=p,
                          seed=seed, stream_id=t["s_att"])
             lib.gemm_tn(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"), accumulate=True)
-            dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=torch.float32)
+            dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
             dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
                                          f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed,
                                          stream_y=t["s_in"], dx1=dx)

@@ -30,7 +30,7 @@ _SIGS = {
     "mrmt3_gemm_tn_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
     "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
-    "mrmt3_add_rmsnorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
+    "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
     "mrmt3_attn_fwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
     "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
                             ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
@@ -45,6 +45,7 @@ _SIGS = {
     "mrmt3_adamw_step": (ci, [vp, vp, vp, vp, csz, vp, vp, cf, cf, cf, cf, cf, vp, vp]),
     "mrmt3_transpose": (ci, [vp, ci, vp, ci, ci, ci, vp]),
     "mrmt3_cast": (ci, [vp, ci, vp, ci, csz, vp]),
+    "mrmt3_transpose_batched": (ci, [vp, vp, vp, vp, ci, ci, vp]),
     "mrmt3_decoder_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci, ci, ci, cf]),
     "mrmt3_decoder_destroy": (None, [vp]),
     "mrmt3_decoder_begin": (ci, [vp, vp, vp, ci, ci, vp, ci, ci, ci, vp]),
@@ -218,7 +219,7 @@ def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, str
     if dx1 is None:
         dx1 = torch.empty_like(x1)
     dy = torch.empty(rows, cols, device=x1.device, dtype=torch.bfloat16) if want_dy else None
-    _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _p(dres), _p(x1), _p(rstd), _p(w), _p(dx1), _p(dy), _p(dw), rows,
+    _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _dt(dxn), _p(dres), _p(x1), _p(rstd), _p(w), _p(dx1), _p(dy), _p(dw), rows,
                                         cols, p, seed, stream_y, stream_out, int(out_drop), _stream()),
            "add_rmsnorm_bwd")
     return dx1, dy
@@ -332,3 +333,9 @@ def cast(src, out):
     _dev(src, out)
     _check(load().mrmt3_cast(_p(src), _dt(src), _p(out), _dt(out), src.numel(), _stream()), "cast")
     return out
+
+
+def transpose_batched(src_flat, dst_flat, desc_table, tile_start, n_mats, total_tiles):
+    _dev(src_flat, dst_flat, desc_table, tile_start)
+    _check(load().mrmt3_transpose_batched(_p(src_flat), _p(dst_flat), _p(desc_table), _p(tile_start), n_mats,
+                                          total_tiles, _stream()), "transpose_batched")

@@ -152,12 +152,26 @@ class FlatParams:
         self._shadow_version = ver
 
     def refresh_transposed(self):
+        """Rebuild every pre-transposed dgrad weight from the bf16 shadow in ONE launch."""
+        import numpy as np
         if self.ST is None or self.ST.device != self.P.device:
             self.ST = torch.empty(self.t_numel, dtype=torch.bfloat16, device=self.P.device)
-        for name, (o, r, c) in self.groups.items():
-            if name == "proj":
-                continue  # the mel input needs no gradient
-            lib.transpose(self.S[o:o + r * c].view(r, c), self.WT(name))
+            self._tr_tab = None
+        if getattr(self, "_tr_tab", None) is None:
+            rec, starts, tot = [], [], 0
+            for name, (o, r, c) in self.groups.items():
+                if name == "proj":
+                    continue  # the mel input needs no gradient
+                rec.append((o, self.t_offsets[name], r, c))
+                starts.append(tot)
+                tot += ((r + 31) // 32) * ((c + 31) // 32)
+            tab = np.zeros(len(rec), dtype=[("src", "<i8"), ("dst", "<i8"), ("rows", "<i4"), ("cols", "<i4")])
+            for i, t in enumerate(rec):
+                tab[i] = t
+            self._tr_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.P.device)
+            self._tr_start = torch.tensor(starts, dtype=torch.int32, device=self.P.device)
+            self._tr_n, self._tr_tiles = len(rec), tot
+        lib.transpose_batched(self.S, self.ST, self._tr_tab, self._tr_start, self._tr_n, self._tr_tiles)
 
     def adamw_step(self, lr_dev, step_dev, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0):
         """torch.optim.AdamW semantics over the whole model in one launch; keeps shadows current."""
