@@ -51,49 +51,48 @@ __device__ __forceinline__ f32x4 mfma_step(f32x4 a, f32x4 b, f32x4 c) {
   return c;
 }
 
-// NT main kernel: 256 x 128 output tile, 8 waves (4 x 2), 3 LDS stages (A 32 KiB + B 16 KiB each),
-// two K-steps of global_load_lds in flight across a raw s_barrier (counted vmcnt, never drained in
-// the loop).  A 128^2 tile needs 64 FLOP per L2 byte -> ~39 TB/s of L2->LDS traffic at the MFMA
-// peak, more than the chip has; 256x128 needs 85 FLOP/B and leaves two tiles of latency cover.
+// NT main kernel: 256 x 128 output tile, 8 waves (4 x 2), K step = 64 bytes of each row (32 bf16 /
+// 16 f32 = one MFMA k-step), 3 LDS stages of 24 KiB (A 16 KiB + B 8 KiB) = 72 KiB, so TWO workgroups
+// share a CU: one's prologue / store epilogue overlaps the other's K loop (K is only 384..2048 here,
+// so with one workgroup per CU the fill and drain were most of the tile time).  Two K-steps of
+// global_load_lds stay in flight across a raw s_barrier (counted vmcnt, never drained in the loop).
+// LDS rows are 64 B; chunk c (16 B) of row r is stored at c ^ (2 * ((r >> 3) & 1)), applied on the
+// glds source address and on the ds_read_b128 fragment reads (conflict-free for the b128 lane groups).
 #define NT_BM 256
 #define NT_BN 128
 #define NT_STAGES 3
-#define NT_STAGE_BYTES ((NT_BM + NT_BN) * ROWB)
+#define NT_ROWB 64
+#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)
 
 template <typename TIN, typename TOUT, bool ACCUM>
-__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
+__global__ __launch_bounds__(512, 4) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
                                                          const TIN* __restrict__ B, int ldb,
                                                          TOUT* __restrict__ C, int ldc, int M, int N,
                                                          int K, int tiles_n) {
-  constexpr int EPC = 16 / sizeof(TIN);    // elements per 16-B chunk
-  constexpr int BK = ROWB / sizeof(TIN);   // elements per K step
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NT_STAGES * NT_STAGE_BYTES];  // 144 KiB, one object
+  constexpr int EPC = 16 / sizeof(TIN);       // elements per 16-B chunk
+  constexpr int BK = NT_ROWB / sizeof(TIN);   // elements per K step
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NT_STAGES * NT_STAGE_BYTES];  // 72 KiB, one object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int wr = uw >> 1, wc = uw & 1;
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (t / tiles_n) * NT_BM, n0 = (t % tiles_n) * NT_BN;
 
-  // staging: A tile = 32 wave-instructions of 1 KiB (8 rows x 128 B), B tile = 16; wave w issues A
-  // instructions 4w..4w+3 and B instructions 2w, 2w+1.  Lane p fills LDS chunk (row = 8t + p/8, c' = p%8)
-  // with global chunk c = c' ^ (row & 7) = (p%8) ^ (p/8)  (swizzle applied on the source address).
-  const int srow = lane >> 3, schunk = (lane & 7) ^ (lane >> 3);
-  const TIN* ga[4];
-  const TIN* gb[2];
+  // staging: one wave-instruction = 1 KiB = 16 rows x 64 B.  A tile = 16 instructions (wave w: 2w, 2w+1),
+  // B tile = 8 (wave w: w).  Lane p fills (row = 16t + p/4, c' = p%4) with global chunk c' ^ (2*((row>>3)&1)).
+  const int srow = lane >> 2, schunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+  const TIN* ga[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ga[i] = A + (size_t)min(m0 + (uw * 4 + i) * 8 + srow, M - 1) * lda + schunk * EPC;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) gb[i] = B + (size_t)min(n0 + (uw * 2 + i) * 8 + srow, N - 1) * ldb + schunk * EPC;
+  for (int i = 0; i < 2; ++i) ga[i] = A + (size_t)min(m0 + (uw * 2 + i) * 16 + srow, M - 1) * lda + schunk * EPC;
+  const TIN* gb = B + (size_t)min(n0 + uw * 16 + srow, N - 1) * ldb + schunk * EPC;
   auto stage = [&](int buf, int k0) {
     unsigned char* base = lds + buf * NT_STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(base + (uw * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(base + NT_BM * ROWB + (uw * 2 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + (uw * 2 + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + k0),
+                                     (__attribute__((address_space(3))) void*)(base + NT_BM * NT_ROWB + uw * 1024), 16, 0, 0);
   };
 
   f32x4 acc[4][4];
@@ -103,76 +102,76 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const TIN* __restrict__
     for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
+  // fragment byte offsets inside a stage (row & 8 is the same for rows i*16 + fr, i = 0..3)
+  const int fswz = (fg ^ (((fr >> 3) & 1) << 1)) << 4;
+  const int offa = (wr * 64 + fr) * NT_ROWB + fswz, offb = NT_BM * NT_ROWB + (wc * 64 + fr) * NT_ROWB + fswz;
   const int nk = K / BK;
   stage(0, 0);
   if (nk > 1) stage(1, BK);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most the 6 loads of tile kt+1 are still outstanding
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // tile kt has landed once at most the 3 loads of tile kt+1 are still outstanding
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading stage (kt-1)%3
     if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);   // (kt+2)%3 == (cur+2)%3
-    const unsigned char* la = lds + cur * NT_STAGE_BYTES;
-    const unsigned char* lb = la + NT_BM * ROWB;
+    const unsigned char* ls = lds + cur * NT_STAGE_BYTES;
+    typename Frag<TIN>::type af[4], bfr[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      typename Frag<TIN>::type af[4], bfr[4];
-      const int c = ks * 4 + fg;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int rowa = wr * 64 + i * 16 + fr;
-        int rowb = wc * 64 + i * 16 + fr;
-        af[i] = *(const typename Frag<TIN>::type*)(la + rowa * ROWB + ((c ^ (rowa & 7)) << 4));
-        bfr[i] = *(const typename Frag<TIN>::type*)(lb + rowb * ROWB + ((c ^ (rowb & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+    for (int i = 0; i < 4; ++i) {
+      af[i] = *(const typename Frag<TIN>::type*)(ls + offa + i * 16 * NT_ROWB);
+      bfr[i] = *(const typename Frag<TIN>::type*)(ls + offb + i * 16 * NT_ROWB);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
     cur = cur == NT_STAGES - 1 ? 0 : cur + 1;
   }
 
   // epilogue.  A lane holds C[row = 16i + 4fg + r][col = 16j + fr]: storing from there means 2/4-byte
   // stores in 32/64-byte pieces, and the store-issue tail then costs more than the whole K loop.
-  // Instead each wave transposes its 64x64 tile through its own slice of the (now idle) staging LDS
-  // and writes whole rows with 16 bytes per lane.
+  // Instead each wave transposes its 64x64 tile through its own slice of the (now idle) staging LDS,
+  // 32 rows at a time, and writes whole rows with 16 bytes per lane.
   __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
   constexpr int EP_LD = 68;                           // floats per LDS row (64 + 4 pad, 16-B aligned rows)
-  float* wl = (float*)(lds + uw * (64 * EP_LD * 4));
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wl[(i * 16 + fg * 4 + r) * EP_LD + j * 16 + fr] = acc[i][j][r];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS round trip: in order, no barrier needed
+  float* wl = (float*)(lds + uw * (32 * EP_LD * 4));  // 8704 B per wave, 69632 B total
   const int rbase = m0 + wr * 64, cbase = n0 + wc * 64;
-  if constexpr (sizeof(TOUT) == 2) {
-    // 64 cols = 128 B per row -> 8 lanes per row, 8 rows per instruction
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int lr = it * 8 + (lane >> 3), lc = (lane & 7) * 8;
-      const f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc), b = *(const f32x4*)(wl + lr * EP_LD + lc + 4);
-      const int row = rbase + lr, col = cbase + lc;
-      if (row < M && col + 8 <= N)
-        *(u32x4*)(C + (size_t)row * ldc + col) =
-            u32x4{pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w)};
-    }
-  } else {
-    // 64 cols = 256 B per row -> 16 lanes per row, 4 rows per instruction
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int lr = it * 4 + (lane >> 4), lc = (lane & 15) * 4;
-      f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc);
-      const int row = rbase + lr, col = cbase + lc;
-      if (row < M && col + 4 <= N) {
-        f32x4* p = (f32x4*)(C + (size_t)row * ldc + col);
-        if (ACCUM) a += *p;
-        *p = a;
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wl[(ii * 16 + fg * 4 + r) * EP_LD + j * 16 + fr] = acc[half * 2 + ii][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS round trip: in order, no barrier needed
+    if constexpr (sizeof(TOUT) == 2) {
+      // 64 cols = 128 B per row -> 8 lanes per row, 8 rows per instruction
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int lr = it * 8 + (lane >> 3), lc = (lane & 7) * 8;
+        const f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc), b = *(const f32x4*)(wl + lr * EP_LD + lc + 4);
+        const int row = rbase + half * 32 + lr, col = cbase + lc;
+        if (row < M && col + 8 <= N)
+          *(u32x4*)(C + (size_t)row * ldc + col) =
+              u32x4{pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w)};
+      }
+    } else {
+      // 64 cols = 256 B per row -> 16 lanes per row, 4 rows per instruction
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 4 + (lane >> 4), lc = (lane & 15) * 4;
+        f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc);
+        const int row = rbase + half * 32 + lr, col = cbase + lc;
+        if (row < M && col + 4 <= N) {
+          f32x4* p = (f32x4*)(C + (size_t)row * ldc + col);
+          if (ACCUM) a += *p;
+          *p = a;
+        }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next half overwrites
   }
 }
 
@@ -192,7 +191,7 @@ extern "C" int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, voi
   MR_CHECK_ARG(A && B && C, "gemm_nt: null pointer");
   MR_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%d N=%d K=%d", M, N, K);
   const int esz = in_dtype == MRMT3_BF16 ? 2 : 4;
-  MR_CHECK_ARG((K * esz) % ROWB == 0, "gemm_nt: K*elem_size must be a multiple of 128 bytes (K=%d)", K);
+  MR_CHECK_ARG((K * esz) % NT_ROWB == 0, "gemm_nt: K*elem_size must be a multiple of 64 bytes (K=%d)", K);
   MR_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "gemm_nt: row strides must be 16-byte multiples");
   {
     const int osz = out_dtype == MRMT3_BF16 ? 2 : 4;

@@ -387,8 +387,8 @@ def test_transpose_cast(dev):
 
 def test_errors_are_reported_not_fatal(dev):
     from mrmt3 import lib
-    a = torch.randn(64, 40, device=dev).bfloat16()   # K*2 not a multiple of 128
-    with pytest.raises(RuntimeError, match="multiple of 128"):
+    a = torch.randn(64, 40, device=dev).bfloat16()   # K*2 not a multiple of 64
+    with pytest.raises(RuntimeError, match="multiple of 64"):
         lib.gemm_nt(a, a)
     with pytest.raises(RuntimeError, match="device tensors"):
         lib.gemm_nt(torch.zeros(128, 64).bfloat16(), torch.zeros(128, 64).bfloat16())
