@@ -83,11 +83,13 @@ int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const flo
  *   g    = dxn (f32 or bf16, dxn_dtype) [* out-dropout mask]
  *   dx1  = dres (nullable) + rmsnorm_bwd(g; x1, rstd, w)          -> dx1 (f32; may alias dres)
  *   dy   = dropmask_y(dx1) as bf16 (nullable)                      -> dy
- *   dw  += sum_rows g * x1 * rstd                                  (f32 atomics into dw[cols]) */
+ *   dw  += sum_rows g * x1 * rstd      (per-workgroup partials in `workspace`, then a 16-way reduction;
+ *                                        workspace >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols)) */
+size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols);
 int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float* dres, const float* x1, const float* rstd,
                           const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
                           float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
-                          int out_drop, void* stream);
+                          int out_drop, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K5: attention core (HF T5Attention without relative bias: softmax(q k^T [+causal]) v, scale
  * 1.0, fp32 softmax; models/t5.py:487-490,636-648) -------------------------------------------------

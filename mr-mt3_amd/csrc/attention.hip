@@ -160,18 +160,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 
   for (int j = 0; j < n_kv; ++j) {
     const int kv0 = j * 64;
-#ifndef ATTN_E3
     if (j + 1 < n_kv) VMCNT(4); else VMCNT(0);      // tile j landed (tile j+1 may still be in flight)
     __builtin_amdgcn_s_barrier();
-#endif
-#ifndef ATTN_E2
     if (j + 2 < n_kv) stage(cur == 0 ? 2 : cur - 1, kv0 + 128);
-#endif
     const unsigned char* lk = lds + cur * KV_STAGE_BYTES;
     const unsigned char* lv = lk + 8192;
-#ifndef ATTN_E2
     cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
-#endif
 
     // causal: a tile that lies entirely above this wave's 32 query rows contributes nothing
     const bool wave_active = !(P.causal && kv0 > q0 + uw * 32 + 31);
@@ -219,11 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#ifdef ATTN_E1
-          const float p = sT[qt][kt][r] * 1e-3f;
-#else
           const float p = __builtin_amdgcn_exp2f(fmaf(sT[qt][kt][r], LOG2E, -m_use));
-#endif
           lsum += p;
           sT[qt][kt][r] = p;
         }

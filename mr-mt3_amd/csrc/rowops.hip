@@ -125,7 +125,7 @@ template <int NV, typename TG>
 __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restrict__ dxn, const float* __restrict__ dres,
                                                               const float* __restrict__ x1, const float* __restrict__ rstd_in,
                                                               const float* __restrict__ w, float* __restrict__ dx1,
-                                                              bf16_t* __restrict__ dy, float* __restrict__ dw, int rows,
+                                                              bf16_t* __restrict__ dy, float* __restrict__ dw_part, int rows,
                                                               int cols, DropCfg ddy, DropCfg dout, int out_drop) {
   __shared__ float red[4 * 256 * NV];  // [wave][col]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -201,25 +201,55 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
       for (int e = 0; e < 4; ++e) redf[wave * cols + i * 256 + lane * 4 + e] = dwp[i][e];
     }
   __syncthreads();
-  if (dw != nullptr)
-    for (int c = threadIdx.x; c < cols; c += 256) {
-      float s = redf[c] + redf[cols + c] + redf[2 * cols + c] + redf[3 * cols + c];
-      atomicAdd(dw + c, s);
+  // per-workgroup partial -> workspace row (no atomics: 2048 workgroups hammering the same 512
+  // addresses ran at the contended-atomic rate); dw_reduce_kernel sums the rows in a fixed order
+  if (dw_part != nullptr)
+    for (int c = threadIdx.x; c < cols; c += 256)
+      dw_part[(size_t)blockIdx.x * cols + c] = redf[c] + redf[cols + c] + redf[2 * cols + c] + redf[3 * cols + c];
+}
+
+// dw[c] += sum over partial rows.  grid = (cols/64, 16 row chunks); a thread = (column, 1 of 4 row
+// groups) streams its rows with independent loads, the workgroup combines through LDS and issues one
+// atomic per column (16 adders per address in total: far from the contended regime).
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                        int n_part, int cols) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int per = (n_part + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(n_part, r0 + per);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int i = r0 + g;
+    for (; i + 4 < r1; i += 8) {
+      s0 += part[(size_t)i * cols + c];
+      s1 += part[(size_t)(i + 4) * cols + c];
     }
+    for (; i < r1; i += 4) s0 += part[(size_t)i * cols + c];
+  }
+  red[g][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && c < cols) atomicAdd(dw + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+extern "C" size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols) {
+  return (size_t)ceil_div(rows, NB_ROWS) * cols * sizeof(float);
 }
 
 extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float* dres, const float* x1, const float* rstd,
                                      const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
                                      float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
-                                     int out_drop, void* stream) {
+                                     int out_drop, void* workspace, size_t workspace_bytes, void* stream) {
+  MR_CHECK_ARG(dw == nullptr || (workspace && workspace_bytes >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols)),
+               "add_rmsnorm_bwd: workspace too small");
+  float* dw_part = dw ? (float*)workspace : nullptr;
   MR_CHECK_ARG(dxn && x1 && rstd && w && dx1, "add_rmsnorm_bwd: null pointer");
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
   DropCfg dy = make_drop(p_drop, seed, stream_y), dn = make_drop(p_drop, seed, stream_out);
 #define LAUNCH2(NV, TG)                                                                                           \
   hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG>), dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0,        \
-                     (hipStream_t)stream, (const TG*)dxn, dres, x1, rstd, w, dx1, (bf16_t*)dy_bf16, dw, rows, cols,   \
-                     dy, dn, out_drop)
+                     (hipStream_t)stream, (const TG*)dxn, dres, x1, rstd, w, dx1, (bf16_t*)dy_bf16, dw_part, rows,    \
+                     cols, dy, dn, out_drop)
 #define LAUNCH(NV)                                       \
   do {                                                   \
     if (dxn_dtype == MRMT3_BF16) LAUNCH2(NV, bf16_t);    \
@@ -232,6 +262,11 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float
 #undef LAUNCH
 #undef LAUNCH2
   MR_CHECK_LAUNCH("add_rmsnorm_bwd");
+  if (dw) {
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)ceil_div(cols, 64), 16), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dw_part, dw, ceil_div(rows, NB_ROWS), cols);
+    MR_CHECK_LAUNCH("add_rmsnorm_bwd dw reduce");
+  }
   return MRMT3_OK;
 }
 
@@ -531,27 +566,24 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     if (dp) for (int c = tid * 4; c < V; c += 1024) { float z[4] = {0.f, 0.f, 0.f, 0.f}; store4<TD>(dp + c, z); }
     return;
   }
-  float mx = -INFINITY;
+  // one pass over the row: running (max, sum of exp) per thread, merged across the workgroup
+  float mx = -INFINITY, se = 0.f;
   for (int c = tid * 4; c < V; c += 1024) {
     float v[4];
     load4<float>(lp + c, v);
-    mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    const float mn = fmaxf(mx, m4);
+    se = se * expf(mx - mn) + ((expf(v[0] - mn) + expf(v[1] - mn)) + (expf(v[2] - mn) + expf(v[3] - mn)));
+    mx = mn;
   }
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
+  const float wmx = wave_max(mx);
+  se = wave_sum(mx == -INFINITY ? 0.f : se * expf(mx - wmx));
+  if (lane == 0) { red[wave] = wmx; red[4 + wave] = se; }
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float se = 0.f;
-  for (int c = tid * 4; c < V; c += 1024) {
-    float v[4];
-    load4<float>(lp + c, v);
+  se = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) se += expf(v[e] - mx);
-  }
-  se = wave_sum(se);
-  if (lane == 0) red[4 + wave] = se;
-  __syncthreads();
-  se = red[4] + red[5] + red[6] + red[7];
+  for (int w4 = 0; w4 < 4; ++w4) se += red[4 + w4] * expf(red[w4] - mx);
   const float lse = mx + logf(se);
   const float inv_den = 1.f / denom[0];
   if (tid == 0) atomicAdd(loss, w * (lse - lp[t]) * inv_den);
@@ -571,11 +603,87 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   }
 }
 
+// fast path for V = NV*256 <= 2048 (MT3: 1536): one WAVE per row, the row lives in registers (one
+// HBM read), statistics by wave shuffles, no LDS and no workgroup barrier.
+template <typename TD, int NV>
+__global__ __launch_bounds__(256) void ce_wave_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                      const float* __restrict__ denom, float* __restrict__ loss,
+                                                      TD* __restrict__ dlogits, int rows, int weighted, int lo, int hi,
+                                                      float grad_scale) {
+  constexpr int V = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* lp = logits + (size_t)row * V;
+  const int64_t t = targets[row];
+  float w, n;
+  ce_weights(t, weighted, lo, hi, &w, &n);
+  TD* dp = dlogits ? dlogits + (size_t)row * V : nullptr;
+  if (w == 0.f) {
+    if (dp) {
+      const float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NV; ++i) store4<TD>(dp + (i * 64 + lane) * 4, z);
+    }
+    return;
+  }
+  float v[NV][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    load4<float>(lp + (i * 64 + lane) * 4, v[i]);
+    mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = expf(v[i][e] - mx);
+      se += v[i][e];
+    }
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  const float inv_den = 1.f / denom[0];
+  if (lane == 0) atomicAdd(loss, w * (lse - lp[t]) * inv_den);
+  if (dp) {
+    const float gs = w * inv_den * grad_scale / se;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      float g[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = v[i][e] * gs - ((c + e == t) ? w * inv_den * grad_scale : 0.f);
+      store4<TD>(dp + c, g);
+    }
+  }
+}
+
 extern "C" int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* denom_dev, float* loss_dev,
                                 void* dlogits, int dl_dtype, int rows, int V, int weighted, int inst_lo,
                                 int inst_hi, float grad_scale, void* stream) {
   MR_CHECK_ARG(logits && targets && denom_dev && loss_dev && rows > 0 && V % 4 == 0, "ce_fwd_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
+  if (V == 1536 || V == 1024 || V == 2048 || V == 512) {
+    dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+#define CEW(TD, NV)                                                                                              \
+  hipLaunchKernelGGL((ce_wave_kernel<TD, NV>), grid, block, 0, s, logits, targets, denom_dev, loss_dev, (TD*)dlogits, \
+                     rows, weighted, inst_lo, inst_hi, grad_scale)
+#define CEV(TD)                                  \
+  do {                                           \
+    if (V == 1536) CEW(TD, 6);                   \
+    else if (V == 1024) CEW(TD, 4);              \
+    else if (V == 2048) CEW(TD, 8);              \
+    else CEW(TD, 2);                             \
+  } while (0)
+    if (dl_dtype == MRMT3_BF16) CEV(bf16_t);
+    else CEV(float);
+#undef CEV
+#undef CEW
+    MR_CHECK_LAUNCH("ce_fwd_bwd");
+    return MRMT3_OK;
+  }
   if (dl_dtype == MRMT3_BF16)
     hipLaunchKernelGGL(ce_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, logits, targets, denom_dev, loss_dev,
                        (bf16_t*)dlogits, rows, V, weighted, inst_lo, inst_hi, grad_scale);

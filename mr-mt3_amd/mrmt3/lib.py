@@ -15,7 +15,7 @@ import torch
 
 F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MRMT3_LIB_PATH") or os.path.join(_HERE, "libmrmt3_hip.so")   # override: tuning experiments only
+LIB_PATH = os.path.join(_HERE, "libmrmt3_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "mrmt3_hip.h")
 CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 _lib = None
@@ -30,7 +30,8 @@ _SIGS = {
     "mrmt3_gemm_tn_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
     "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
-    "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
+    "mrmt3_add_rmsnorm_bwd_workspace_bytes": (csz, [ci, ci]),
+    "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp, csz, vp]),
     "mrmt3_attn_fwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
     "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
                             ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
@@ -219,9 +220,10 @@ def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, str
     if dx1 is None:
         dx1 = torch.empty_like(x1)
     dy = torch.empty(rows, cols, device=x1.device, dtype=torch.bfloat16) if want_dy else None
+    ws = workspace(load().mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols), x1.device)
     _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _dt(dxn), _p(dres), _p(x1), _p(rstd), _p(w), _p(dx1), _p(dy), _p(dw), rows,
-                                        cols, p, seed, stream_y, stream_out, int(out_drop), _stream()),
-           "add_rmsnorm_bwd")
+                                        cols, p, seed, stream_y, stream_out, int(out_drop), _p(ws), ws.numel(),
+                                        _stream()), "add_rmsnorm_bwd")
     return dx1, dy
 
 
