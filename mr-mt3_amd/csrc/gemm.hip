@@ -51,48 +51,63 @@ __device__ __forceinline__ f32x4 mfma_step(f32x4 a, f32x4 b, f32x4 c) {
   return c;
 }
 
-// NT main kernel: 256 x 128 output tile, 8 waves (4 x 2), K step = 64 bytes of each row (32 bf16 /
-// 16 f32 = one MFMA k-step), 3 LDS stages of 24 KiB (A 16 KiB + B 8 KiB) = 72 KiB, so TWO workgroups
-// share a CU: one's prologue / store epilogue overlaps the other's K loop (K is only 384..2048 here,
-// so with one workgroup per CU the fill and drain were most of the tile time).  Two K-steps of
-// global_load_lds stay in flight across a raw s_barrier (counted vmcnt, never drained in the loop).
+// NT main kernel, templated on the wave grid WM x WN (each wave owns a 64x64 output sub-tile = 4x4 MFMA
+// tiles): workgroup tile = 64*WM x 64*WN.  K step = 64 bytes of each row (32 bf16 / 16 f32 = one MFMA
+// k-step), 3 LDS stages, two K-steps of global_load_lds in flight across a raw s_barrier (counted vmcnt,
+// never drained in the loop).
+// Measured on MI355X: this kernel family runs at a constant ~9 TB/s of L2->LDS staging traffic whatever
+// the tile (128^2: 64 FLOP/B -> 570 TF, 256x128: 85 FLOP/B -> 720-820 TF), so the lever is FLOP per staged
+// byte = BM*BN/(BM+BN):
+//   <4,4>  256x256 (128 FLOP/B), 16 waves, 2 x 64 KiB stages (128-B K steps), one workgroup per CU — N % 256 == 0
+//   <4,2>  256x128 ( 85 FLOP/B),  8 waves, 3 x 24 KiB stages, two workgroups per CU — the other shapes
 // LDS rows are 64 B; chunk c (16 B) of row r is stored at c ^ (2 * ((r >> 3) & 1)), applied on the
 // glds source address and on the ds_read_b128 fragment reads (conflict-free for the b128 lane groups).
-#define NT_BM 256
-#define NT_BN 128
-#define NT_STAGES 3
-#define NT_ROWB 64
-#define NT_STAGE_BYTES ((NT_BM + NT_BN) * NT_ROWB)
+// pipeline of the 256x256 tile: 128-B K steps x 2 stages measured 2-9 % faster than 64 B x 3 stages
+#define NT_RB_BIG 128
+#define NT_ST_BIG 2
 
-template <typename TIN, typename TOUT, bool ACCUM>
-__global__ __launch_bounds__(512, 4) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
-                                                         const TIN* __restrict__ B, int ldb,
-                                                         TOUT* __restrict__ C, int ldc, int M, int N,
-                                                         int K, int tiles_n) {
+template <typename TIN, typename TOUT, bool ACCUM, int WM, int WN, int RB, int NST>
+__global__ __launch_bounds__(64 * WM * WN, 4) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
+                                                                   const TIN* __restrict__ B, int ldb,
+                                                                   TOUT* __restrict__ C, int ldc, int M, int N,
+                                                                   int K, int tiles_n) {
+  constexpr int BM = 64 * WM, BN = 64 * WN, NWAVES = WM * WN;
+  constexpr int STAGE_BYTES = (BM + BN) * RB;
+  constexpr int RPI = 1024 / RB;              // rows per 1-KiB wave-instruction (16 or 8)
+  constexpr int CPR = RB / 16;                // 16-B chunks per row (4 or 8)
+  constexpr int A_INSTR = BM / RPI, TOT_INSTR = (BM + BN) / RPI, PER_WAVE = TOT_INSTR / NWAVES;
+  static_assert(TOT_INSTR % NWAVES == 0, "staging instructions must divide evenly over the waves");
+  static_assert((RB == 64 && NST == 3) || (RB == 128 && NST == 2), "supported pipelines: 64 B x 3 stages, 128 B x 2 stages");
   constexpr int EPC = 16 / sizeof(TIN);       // elements per 16-B chunk
-  constexpr int BK = NT_ROWB / sizeof(TIN);   // elements per K step
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NT_STAGES * NT_STAGE_BYTES];  // 72 KiB, one object
+  constexpr int BK = RB / sizeof(TIN);        // elements per K step
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];  // one object
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
-  const int wr = uw >> 1, wc = uw & 1;
+  const int wr = uw / WN, wc = uw % WN;
   const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (t / tiles_n) * NT_BM, n0 = (t % tiles_n) * NT_BN;
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
 
-  // staging: one wave-instruction = 1 KiB = 16 rows x 64 B.  A tile = 16 instructions (wave w: 2w, 2w+1),
-  // B tile = 8 (wave w: w).  Lane p fills (row = 16t + p/4, c' = p%4) with global chunk c' ^ (2*((row>>3)&1)).
-  const int srow = lane >> 2, schunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
-  const TIN* ga[2];
+  // staging: one wave-instruction = 1 KiB = 16 rows x 64 B; instruction q < A_INSTR fills A rows 16q..,
+  // the rest B rows.  Wave w issues q = w, w + NWAVES, ...  Lane p fills (row = 16q + p/4, c' = p%4)
+  // with global chunk c' ^ (2*((row>>3)&1)).
+  // (128-B rows: 8 rows per instruction, chunk c stored at c ^ (row & 7).)
+  const int srow = lane / CPR;
+  const int schunk = (RB == 64) ? ((lane & 3) ^ (((lane >> 5) & 1) << 1)) : ((lane & 7) ^ (lane >> 3));
+  const TIN* gsrc[PER_WAVE];
+  int ldst[PER_WAVE];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) ga[i] = A + (size_t)min(m0 + (uw * 2 + i) * 16 + srow, M - 1) * lda + schunk * EPC;
-  const TIN* gb = B + (size_t)min(n0 + uw * 16 + srow, N - 1) * ldb + schunk * EPC;
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int q = uw + NWAVES * i;
+    if (q < A_INSTR) gsrc[i] = A + (size_t)min(m0 + q * RPI + srow, M - 1) * lda + schunk * EPC;
+    else gsrc[i] = B + (size_t)min(n0 + (q - A_INSTR) * RPI + srow, N - 1) * ldb + schunk * EPC;
+    ldst[i] = q * 1024;
+  }
   auto stage = [&](int buf, int k0) {
-    unsigned char* base = lds + buf * NT_STAGE_BYTES;
+    unsigned char* base = lds + buf * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(base + (uw * 2 + i) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + k0),
-                                     (__attribute__((address_space(3))) void*)(base + NT_BM * NT_ROWB + uw * 1024), 16, 0, 0);
+    for (int i = 0; i < PER_WAVE; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + ldst[i]), 16, 0, 0);
   };
 
   f32x4 acc[4][4];
@@ -102,57 +117,93 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(const TIN* __restrict__
     for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
-  // fragment byte offsets inside a stage (row & 8 is the same for rows i*16 + fr, i = 0..3)
-  const int fswz = (fg ^ (((fr >> 3) & 1) << 1)) << 4;
-  const int offa = (wr * 64 + fr) * NT_ROWB + fswz, offb = NT_BM * NT_ROWB + (wc * 64 + fr) * NT_ROWB + fswz;
   const int nk = K / BK;
-  stage(0, 0);
-  if (nk > 1) stage(1, BK);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most the 3 loads of tile kt+1 are still outstanding
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading stage (kt-1)%3
-    if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);   // (kt+2)%3 == (cur+2)%3
-    const unsigned char* ls = lds + cur * NT_STAGE_BYTES;
-    typename Frag<TIN>::type af[4], bfr[4];
+  if constexpr (RB == 64) {
+    // fragment byte offsets inside a stage (row & 8 is the same for rows i*16 + fr, i = 0..3)
+    const int fswz = (fg ^ (((fr >> 3) & 1) << 1)) << 4;
+    const int offa = (wr * 64 + fr) * RB + fswz, offb = BM * RB + (wc * 64 + fr) * RB + fswz;
+    stage(0, 0);
+    if (nk > 1) stage(1, BK);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed once at most the PER_WAVE loads of tile kt+1 are still outstanding
+      if (kt + 1 < nk) {
+        if (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading stage (kt-1)%3
+      if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);   // (kt+2)%3 == (cur+2)%3
+      const unsigned char* ls = lds + cur * STAGE_BYTES;
+      typename Frag<TIN>::type af[4], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i] = *(const typename Frag<TIN>::type*)(ls + offa + i * 16 * NT_ROWB);
-      bfr[i] = *(const typename Frag<TIN>::type*)(ls + offb + i * 16 * NT_ROWB);
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const typename Frag<TIN>::type*)(ls + offa + i * 16 * RB);
+        bfr[i] = *(const typename Frag<TIN>::type*)(ls + offb + i * 16 * RB);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+      cur = cur == NST - 1 ? 0 : cur + 1;
     }
+  } else {
+    // 128-B rows, two stages: 32 MFMAs per wave per barrier; the next K step is issued right after the
+    // barrier and lands during this step's MFMAs
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+      const unsigned char* la = lds + cur * STAGE_BYTES;
+      const unsigned char* lb = la + BM * RB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int ks = 0; ks < 2; ++ks) {
+        typename Frag<TIN>::type af[4], bfr[4];
+        const int c = ks * 4 + fg;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
-    cur = cur == NT_STAGES - 1 ? 0 : cur + 1;
+        for (int i = 0; i < 4; ++i) {
+          const int rowa = wr * 64 + i * 16 + fr, rowb = wc * 64 + i * 16 + fr;
+          af[i] = *(const typename Frag<TIN>::type*)(la + rowa * RB + ((c ^ (rowa & 7)) << 4));
+          bfr[i] = *(const typename Frag<TIN>::type*)(lb + rowb * RB + ((c ^ (rowb & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma_step(af[i], bfr[j], acc[i][j]);
+      }
+    }
   }
 
   // epilogue.  A lane holds C[row = 16i + 4fg + r][col = 16j + fr]: storing from there means 2/4-byte
   // stores in 32/64-byte pieces, and the store-issue tail then costs more than the whole K loop.
   // Instead each wave transposes its 64x64 tile through its own slice of the (now idle) staging LDS,
-  // 32 rows at a time, and writes whole rows with 16 bytes per lane.
+  // EP_ROWS rows at a time, and writes whole rows with 16 bytes per lane.
   __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
   constexpr int EP_LD = 68;                           // floats per LDS row (64 + 4 pad, 16-B aligned rows)
-  float* wl = (float*)(lds + uw * (32 * EP_LD * 4));  // 8704 B per wave, 69632 B total
+  constexpr int EP_ROWS = (NST * STAGE_BYTES / NWAVES >= 32 * EP_LD * 4) ? 32 : 16;
+  static_assert(NST * STAGE_BYTES / NWAVES >= EP_ROWS * EP_LD * 4, "epilogue slice does not fit");
+  float* wl = (float*)(lds + uw * (EP_ROWS * EP_LD * 4));
   const int rbase = m0 + wr * 64, cbase = n0 + wc * 64;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int part = 0; part < 64 / EP_ROWS; ++part) {
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+    for (int ii = 0; ii < EP_ROWS / 16; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) wl[(ii * 16 + fg * 4 + r) * EP_LD + j * 16 + fr] = acc[half * 2 + ii][j][r];
+        for (int r = 0; r < 4; ++r)
+          wl[(ii * 16 + fg * 4 + r) * EP_LD + j * 16 + fr] = acc[part * (EP_ROWS / 16) + ii][j][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS round trip: in order, no barrier needed
     if constexpr (sizeof(TOUT) == 2) {
       // 64 cols = 128 B per row -> 8 lanes per row, 8 rows per instruction
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < EP_ROWS / 8; ++it) {
         const int lr = it * 8 + (lane >> 3), lc = (lane & 7) * 8;
         const f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc), b = *(const f32x4*)(wl + lr * EP_LD + lc + 4);
-        const int row = rbase + half * 32 + lr, col = cbase + lc;
+        const int row = rbase + part * EP_ROWS + lr, col = cbase + lc;
         if (row < M && col + 8 <= N)
           *(u32x4*)(C + (size_t)row * ldc + col) =
               u32x4{pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w)};
@@ -160,10 +211,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(const TIN* __restrict__
     } else {
       // 64 cols = 256 B per row -> 16 lanes per row, 4 rows per instruction
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < EP_ROWS / 4; ++it) {
         const int lr = it * 4 + (lane >> 4), lc = (lane & 15) * 4;
         f32x4 a = *(const f32x4*)(wl + lr * EP_LD + lc);
-        const int row = rbase + half * 32 + lr, col = cbase + lc;
+        const int row = rbase + part * EP_ROWS + lr, col = cbase + lc;
         if (row < M && col + 4 <= N) {
           f32x4* p = (f32x4*)(C + (size_t)row * ldc + col);
           if (ACCUM) a += *p;
@@ -171,17 +222,22 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(const TIN* __restrict__
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next half overwrites
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next part overwrites
   }
 }
 
 template <typename TIN, typename TOUT, bool ACCUM>
 static int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      hipStream_t s) {
-  const int tiles_m = ceil_div(M, NT_BM), tiles_n = ceil_div(N, NT_BN);
-  dim3 grid((unsigned)(tiles_m * tiles_n)), block(512);
-  hipLaunchKernelGGL((gemm_nt_kernel<TIN, TOUT, ACCUM>), grid, block, 0, s, (const TIN*)A, lda, (const TIN*)B, ldb,
-                     (TOUT*)C, ldc, M, N, K, tiles_n);
+  if (N % 256 == 0 && M >= 2048 && (K * sizeof(TIN)) % NT_RB_BIG == 0) {
+    const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
+    hipLaunchKernelGGL((gemm_nt_kernel<TIN, TOUT, ACCUM, 4, 4, NT_RB_BIG, NT_ST_BIG>), dim3((unsigned)(tiles_m * tiles_n)), dim3(1024), 0, s,
+                       (const TIN*)A, lda, (const TIN*)B, ldb, (TOUT*)C, ldc, M, N, K, tiles_n);
+  } else {
+    const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128);
+    hipLaunchKernelGGL((gemm_nt_kernel<TIN, TOUT, ACCUM, 4, 2, 64, 3>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, s,
+                       (const TIN*)A, lda, (const TIN*)B, ldb, (TOUT*)C, ldc, M, N, K, tiles_n);
+  }
   MR_CHECK_LAUNCH("gemm_nt");
   return MRMT3_OK;
 }
@@ -191,7 +247,7 @@ extern "C" int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, voi
   MR_CHECK_ARG(A && B && C, "gemm_nt: null pointer");
   MR_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%d N=%d K=%d", M, N, K);
   const int esz = in_dtype == MRMT3_BF16 ? 2 : 4;
-  MR_CHECK_ARG((K * esz) % NT_ROWB == 0, "gemm_nt: K*elem_size must be a multiple of 64 bytes (K=%d)", K);
+  MR_CHECK_ARG((K * esz) % 64 == 0, "gemm_nt: K*elem_size must be a multiple of 64 bytes (K=%d)", K);
   MR_CHECK_ARG((lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0, "gemm_nt: row strides must be 16-byte multiples");
   {
     const int osz = out_dtype == MRMT3_BF16 ? 2 : 4;

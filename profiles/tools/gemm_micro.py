@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "mr-mt3_amd"))
 import torch
 from mrmt3 import lib
+if os.environ.get("MRMT3_TOOL_LIB"):      # tuning tool only: A/B a variant build of the library
+    lib.LIB_PATH = os.environ["MRMT3_TOOL_LIB"]
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
