@@ -188,8 +188,10 @@ def main():
         "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
     }
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings
         fam = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), max(1, min(args.steps, 3)))
+    if rank == 0 and not args.no_roofline:
         total = sum(f["ms"] for f in fam.values())
         dom = max((k for k in fam if fam[k]["unit"] == "FLOP"), key=lambda k: fam[k]["ms"])
         f = fam[dom]
