@@ -177,7 +177,7 @@ def generate(model, inputs, max_length=1024, poll_every=64):
     dec = _decoder_for(model, 1, max_length, Le + Ls)
     outs = []
     for i in range(B):
-        mem = eng.segmem(seg_ids, 1, max_length).view(1, max_length, d)[:, :Ls]
+        mem = eng.segmem(seg_ids, 1, max_length)                           # [1, Ls, d]
         cur = torch.cat([enc.view(B, Le, d)[i:i + 1], mem], 1).contiguous().view(Le + Ls, d)
         ckv = dec.cross_kv(cur, 1, Le + Ls)
         toks, done, fin = dec.run(ckv, 1, Le + Ls, max_length, poll_every)

@@ -228,25 +228,90 @@ class Engine:
         """embed -> segmem_proj -> 1-layer bidirectional encoder, dropout 0
         (models/t5_segmem.py:56-66, models/t5_segmem_v2_with_prev.py:121-123; the positional call
         `self.segmem_encoder(segmem_embeds)` routes the embeddings through `embed_tokens` =
-        segmem_proj).  Returns all L positions [B*L, d] in the compute dtype."""
-        f = self.flat
+        segmem_proj).  Returns the first `segmem_length` positions [B, Ls, d] in the compute dtype.
+
+        Only those Ls outputs are ever used (`[:, :self.segmem_length]`), so for the reference's
+        one-layer memory encoder the computation is restricted EXACTLY: keys/values need all L
+        positions, but queries, the O projection, the feed-forward and the final norm only the first
+        Ls rows (6.4 -> ~1 GFLOP per segment, SURVEY §7 "segmem-encoder shortcut")."""
+        f, dt, d, H, inner, eps = self.flat, self.dt, self.d, self.H, self.inner, self.eps
+        Ls = min(self.segmem_length, L)
         emb = lib.embed_fwd(ids.reshape(-1), f.master("decoder_embed_tokens.weight"), None, L, shift=False,
                             pad_id=self.cfg["pad_token_id"])
         emb_a = self._act(emb)
         src = lib.gemm_nt(emb_a, self.W("segmem_proj"), out_dtype=self.y_dtype)
         x = lib.addpos_fwd(src, self.pos(ids.device), L)
+        if self.segmem_num_layers != 1:
+            if tape is not None:
+                tape.push(kind="seg_in", ids=ids.reshape(-1), emb=emb_a, L=L, short=False, Ls=Ls, B=B)
+            full = self.stack_fwd("segmem_encoder", x, B, L, self.segmem_num_layers, False, p=0.0, tape=tape)
+            return full.view(B, L, d)[:, :Ls]
+        pre, b = "segmem_encoder", "segmem_encoder.block.0.layer"
+        Wqkv = self.W(f"{pre}.0.qkv")
+        _, xn_full, rstd_full = lib.add_rmsnorm_fwd(x, None, self.ln(f"{b}.0.layer_norm.weight"), eps, dt, write_x1=False)
+        kv = lib.gemm_nt(xn_full, Wqkv[inner:])                                     # [B*L, 2*inner]
+        xs = x.view(B, L, d)[:, :Ls].contiguous().view(B * Ls, d)
+        xns = xn_full.view(B, L, d)[:, :Ls].contiguous().view(B * Ls, d)
+        q = lib.gemm_nt(xns, Wqkv[:inner])
+        o, lse = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, Ls, L, False, want_lse=tape is not None)
+        y = lib.gemm_nt(o, self.W(f"{pre}.0.o"), out_dtype=self.y_dtype)
+        x1, xn1, rstd1 = lib.add_rmsnorm_fwd(xs, y, self.ln(f"{b}.1.layer_norm.weight"), eps, dt)
+        h = lib.gemm_nt(xn1, self.W(f"{pre}.0.wi"))
+        g = lib.geglu_fwd(h)
+        y2 = lib.gemm_nt(g, self.W(f"{pre}.0.wo"), out_dtype=self.y_dtype)
+        x2, out, rstd2 = lib.add_rmsnorm_fwd(x1, y2, self.ln(f"{pre}.final_layer_norm.weight"), eps, dt)
         if tape is not None:
-            tape.push(kind="seg_in", ids=ids.reshape(-1), emb=emb_a, L=L)
-        return self.stack_fwd("segmem_encoder", x, B, L, self.segmem_num_layers, False, p=0.0, tape=tape)
+            tape.push(kind="seg_in", ids=ids.reshape(-1), emb=emb_a, L=L, short=True, Ls=Ls, B=B, x=x,
+                      xn_full=xn_full, rstd_full=rstd_full, kv=kv, xns=xns, q=q, o=o, lse=lse, x1=x1, xn1=xn1,
+                      rstd1=rstd1, h=h, g=g, x2=x2, rstd2=rstd2)
+        return out.view(B, Ls, d)
 
-    def segmem_bwd(self, tape, d_mem_full):
-        dx = self.stack_bwd(tape, d_mem_full)
-        t = tape.pop()
+    def segmem_bwd(self, tape, d_mem):
+        """d_mem: fp32 [B, Ls, d] gradient w.r.t. the memory vectors."""
+        f, d, H, inner = self.flat, self.d, self.H, self.inner
+        if tape.ops[-1]["kind"] != "seg_in":                    # generic multi-layer path
+            fin = next(o for o in reversed(tape.ops) if o["kind"] == "seg_in")
+            B, L, Ls = fin["B"], fin["L"], fin["Ls"]
+            d_full = torch.zeros(B, L, d, device=d_mem.device, dtype=torch.float32)
+            d_full[:, :Ls] = d_mem
+            dx = self.stack_bwd(tape, d_full.view(B * L, d))
+            t = tape.pop()
+        else:
+            t = tape.pop()
+            B, L, Ls = t["B"], t["L"], t["Ls"]
+            pre, b = "segmem_encoder", "segmem_encoder.block.0.layer"
+            GW, WT = f.GW(f"{pre}.0.qkv"), f.WT(f"{pre}.0.qkv")
+            d_out = d_mem.contiguous().view(B * Ls, d)
+            dx2, dy2 = lib.add_rmsnorm_bwd(d_out, None, t["x2"], t["rstd2"], self.ln(f"{pre}.final_layer_norm.weight"),
+                                           f.grad(f"{pre}.final_layer_norm.weight"))
+            lib.gemm_tn(dy2, t["g"], f.GW(f"{pre}.0.wo"), accumulate=True)
+            dg = lib.gemm_nt(dy2, f.WT(f"{pre}.0.wo"))
+            dh = lib.geglu_bwd(t["h"], dg)
+            lib.gemm_tn(dh, t["xn1"], f.GW(f"{pre}.0.wi"), accumulate=True)
+            dxn1 = lib.gemm_nt(dh, f.WT(f"{pre}.0.wi"), out_dtype=self.y_dtype)
+            dx1, dy = lib.add_rmsnorm_bwd(dxn1, dx2, t["x1"], t["rstd1"], self.ln(f"{b}.1.layer_norm.weight"),
+                                          f.grad(f"{b}.1.layer_norm.weight"), dx1=dx2)
+            lib.gemm_tn(dy, t["o"], f.GW(f"{pre}.0.o"), accumulate=True)
+            do = lib.gemm_nt(dy, f.WT(f"{pre}.0.o"))
+            kv = t["kv"]
+            dq, dkv = torch.empty_like(t["q"]), torch.empty_like(kv)
+            lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
+                         dkv[:, inner:], B, H, Ls, L, False)
+            lib.gemm_tn(dq, t["xns"], GW[:inner], accumulate=True)
+            lib.gemm_tn(dkv, t["xn_full"], GW[inner:], accumulate=True)
+            dxn_full = lib.gemm_nt(dkv, WT[:, inner:], out_dtype=torch.float32)          # [B*L, d]
+            dxns = lib.gemm_nt(dq, WT[:, :inner], out_dtype=torch.float32)               # [B*Ls, d]
+            dxn_full.view(B, L, d)[:, :Ls] += dxns.view(B, Ls, d)
+            dres = torch.zeros(B, L, d, device=dx1.device, dtype=torch.float32)
+            dres[:, :Ls] = dx1.view(B, Ls, d)
+            dx, _ = lib.add_rmsnorm_bwd(dxn_full, dres.view(B * L, d), t["x"], t["rstd_full"],
+                                        self.ln(f"{b}.0.layer_norm.weight"), f.grad(f"{b}.0.layer_norm.weight"),
+                                        want_dy=False)
         assert t["kind"] == "seg_in"
         dsrc = lib.dropmask_cast(dx)
-        lib.gemm_tn(dsrc, t["emb"], self.flat.GW("segmem_proj"), accumulate=True)
-        demb = lib.gemm_nt(dsrc, self.flat.WT("segmem_proj"), out_dtype=torch.float32)
-        lib.embed_bwd(t["ids"], demb, self.flat.grad("decoder_embed_tokens.weight"), t["L"], shift=False,
+        lib.gemm_tn(dsrc, t["emb"], f.GW("segmem_proj"), accumulate=True)
+        demb = lib.gemm_nt(dsrc, f.WT("segmem_proj"), out_dtype=torch.float32)
+        lib.embed_bwd(t["ids"], demb, f.grad("decoder_embed_tokens.weight"), t["L"], shift=False,
                       pad_id=self.cfg["pad_token_id"])
 
     @staticmethod
@@ -289,8 +354,8 @@ class Engine:
             else:
                 ids = self.prev_row_ids(labels, start, pad)
             Lm = ids.shape[1]
-            mem_full = self.segmem(ids, B, Lm, tape=tape)                        # [B*Lm, d]
-            mem = mem_full.view(B, Lm, d)[:, :Ls]
+            mem = self.segmem(ids, B, Lm, tape=tape)                             # [B, Ls, d]
+            Ls = mem.shape[1]
         s_emb = self._sid()
         if variant == "segmem_v1":
             # memory is PREPENDED to the decoder input embeddings (t5_segmem.py:138-160)
@@ -309,7 +374,7 @@ class Engine:
             else:
                 enc_cat, Lc = enc, Le
         if tape is not None:
-            tape.push(kind="dec_in", s_emb=s_emb, p=p, labels=labels, B=B, Le=Le, Ld=Ld, Lx=Lx, Lc=Lc,
+            tape.push(kind="dec_in", s_emb=s_emb, p=p, labels=labels, B=B, Le=Le, Ld=Ld, Lx=Lx, Lc=Lc, Ls=Ls,
                       Lm=(ids.shape[1] if variant != "t5" else 0))
         dec = self.stack_fwd("decoder", x, B, Lx, cfg["num_decoder_layers"], True, enc=enc_cat, Le=Lc, p=p, tape=tape)
         if variant == "segmem_v1":
@@ -334,7 +399,7 @@ class Engine:
             on_layer_done("lm_head", 0)
         # peek the decoder-input record (it sits below the decoder stack's records)
         din = next(o for o in reversed(tape.ops) if o["kind"] == "dec_in")
-        B, Le, Ld, Lx, Lc = din["B"], din["Le"], din["Ld"], din["Lx"], din["Lc"]
+        B, Le, Ld, Lx, Lc, Ls = din["B"], din["Le"], din["Ld"], din["Lx"], din["Lc"], din["Ls"]
         if variant == "segmem_v1":
             full = torch.zeros(B, Lx, d, device=d_dec.device, dtype=torch.float32)
             full[:, Ls:] = d_dec.view(B, Ld, d)
@@ -362,9 +427,6 @@ class Engine:
             else:
                 d_enc = d_enc_cat
         if d_mem is not None:
-            Lm = t["Lm"]
-            d_full = torch.zeros(B, Lm, d, device=dx.device, dtype=torch.float32)
-            d_full[:, :Ls] = d_mem
-            self.segmem_bwd(tape, d_full.view(B * Lm, d))
+            self.segmem_bwd(tape, d_mem)
         self.encode_bwd(tape, d_enc, on_layer_done=on_layer_done)
         assert not tape.ops, [o["kind"] for o in tape.ops]
