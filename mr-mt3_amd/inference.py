@@ -6,9 +6,10 @@
     each segment's spectrogram on the CPU main process, rebuilding the filterbank per call).
   * `inference`: `model.generate` is the KV-cached hipGraph decoder; `_postprocess_batch` is
     unchanged arithmetic on the returned ids.
-Event decoding to notes / MIDI writing (`_to_event`, inference.py:217-234) needs note_seq and the
-MT3 codec and is the next row of the scope table; `inference()` therefore
-returns the post-processed token arrays and frame times instead of writing a MIDI file.
+  * `_to_event` / MIDI writing (inference.py:217-234, 195-201): the codec, the run-length decoder and
+    the note state machine are restated without note_seq/seqio (`contrib/{event_codec,vocabularies,
+    run_length_encoding,note_sequences,metrics_utils,midi_io}.py`); `inference(..., outpath=...)`
+    writes a Standard MIDI File and returns the note sequence.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import math
 import numpy as np
 import torch
 
-from contrib import spectrograms
+from contrib import metrics_utils, midi_io, note_sequences, spectrograms, vocabularies
 
 MIN_LOG_MEL = -12
 MAX_LOG_MEL = 5
@@ -74,6 +75,7 @@ class InferenceHandler:
         self.contiguous_inference = contiguous_inference
         self.SAMPLE_RATE = 16000
         self.spectrogram_config = spectrograms.SpectrogramConfig()
+        self.codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))   # inference.py:52-53
         self.device = device
         self.model.to(self.device)
         self.mel_norm = mel_norm
@@ -109,10 +111,27 @@ class InferenceHandler:
     def _postprocess_batch(self, result):
         return postprocess_batch(result, self.model.config.eos_token_id)
 
+    def _to_event(self, predictions_np, frame_times):
+        """inference.py:217-234 — per segment: cut at the first decoded EOS (-1), segment start time =
+        first frame time rounded down to the codec step, then decode all segments with ties."""
+        predictions = []
+        for i, batch in enumerate(predictions_np):
+            for j, tokens in enumerate(batch):
+                # NB (kept from the reference): argmax of an all-False mask is 0, so a segment that
+                # never emitted EOS contributes NO tokens.
+                tokens = tokens[:np.argmax(tokens == vocabularies.DECODED_EOS_ID)]
+                start_time = frame_times[i][j][0]
+                start_time -= start_time % (1 / self.codec.steps_per_second)
+                predictions.append({"est_tokens": tokens, "start_time": start_time, "raw_inputs": []})
+        result = metrics_utils.event_predictions_to_ns(predictions, codec=self.codec,
+                                                       encoding_spec=note_sequences.NoteEncodingWithTiesSpec)
+        return result["est_ns"]
+
     @torch.no_grad()
     def inference(self, audio, audio_path=None, outpath=None, valid_programs=None, num_beams=1, batch_size=5,
-                  max_length=1024, verbose=False):
-        """Returns (list of post-processed token arrays per batch, list of frame-time arrays)."""
+                  max_length=1024, verbose=False, return_tokens=False):
+        """audio -> note sequence (and a MIDI file when `outpath` is given, like inference.py:149-204).
+        `return_tokens=True` returns (post-processed token arrays per batch, frame times) instead."""
         inputs, frame_times = self._preprocess(audio)
         batches, ft = self._batching(inputs, frame_times, batch_size=batch_size)
         if self.contiguous_inference:
@@ -122,4 +141,11 @@ class InferenceHandler:
         for batch in batches:
             result = self.model.generate(inputs=batch.to(self.device), max_length=max_length)
             results.append(self._postprocess_batch(result))
-        return results, ft
+        if return_tokens:
+            return results, ft
+        ns = self._to_event(results, ft)
+        if outpath is not None:
+            import os
+            os.makedirs(os.path.dirname(os.path.abspath(outpath)), exist_ok=True)
+            midi_io.note_sequence_to_midi_file(ns, outpath)
+        return ns

@@ -1,0 +1,165 @@
+"""ORACLE (test infrastructure, not product code) — literal CPU restatement of the reference's token ->
+note post-processing, used to check `mr-mt3_amd/contrib/{event_codec,run_length_encoding,
+note_sequences,metrics_utils}.py`.
+
+Follows: contrib/event_codec.py:34-112 (Codec: linear scan over ranges), contrib/vocabularies.py:54-68,
+118-139 (bin_to_velocity, build_codec), contrib/run_length_encoding.py:192-247 (decode_events),
+contrib/note_sequences.py:24-28,68-80,258-393 (state machine, assign_instruments, flush),
+contrib/metrics_utils.py:50-143, inference.py:217-234 (_to_event).
+
+PARITY PINNING: `contrib/event_codec.py` has no third-party imports, so the codec tables are pinned
+against the reference itself (tests/golden/codec_golden.json, written by make_golden.py).  The note
+state machine lives in modules that import note_seq (absent from /root/reference and the image):
+it is pinned only by hand-derived known answers -> "parity unpinned (restated from the cited lines)".
+Notes are plain tuples (start, end, pitch, velocity, program, is_drum, instrument).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RANGES_V1 = [("shift", 0, 1000), ("pitch", 0, 127), ("velocity", 0, 1), ("tie", 0, 0), ("program", 0, 127),
+             ("drum", 0, 127)]           # build_codec(VocabularyConfig(num_velocity_bins=1))
+STEPS_PER_SECOND = 100
+DEFAULT_NOTE_DURATION = MIN_NOTE_DURATION = 0.01
+
+
+def decode_index(index, ranges=RANGES_V1):
+    off = 0
+    for name, lo, hi in ranges:
+        if off <= index <= off + hi - lo:
+            return name, lo + index - off
+        off += hi - lo + 1
+    raise ValueError(index)
+
+
+def type_range(name, ranges=RANGES_V1):
+    off = 0
+    for n, lo, hi in ranges:
+        if n == name:
+            return off, off + (hi - lo)
+        off += hi - lo + 1
+    raise ValueError(name)
+
+
+class State:
+    def __init__(self):
+        self.current_time, self.velocity, self.program = 0.0, 100, 0
+        self.active, self.tied, self.tie_section = {}, set(), False
+        self.notes, self.total_time = [], 0.0
+
+
+def _add(st, start, end, pitch, vel, program=0, is_drum=False):
+    end = max(end, start + MIN_NOTE_DURATION)
+    st.notes.append([start, end, int(pitch), int(vel), int(program), is_drum, 0])
+    st.total_time = max(st.total_time, end)
+
+
+def decode_note_event(st, time, etype, value, ranges=RANGES_V1):
+    if time < st.current_time:
+        raise ValueError("time")
+    st.current_time = time
+    if etype == "pitch":
+        key = (value, st.program)
+        if st.tie_section:
+            if key not in st.active or key in st.tied:
+                raise ValueError("tie")
+            st.tied.add(key)
+        elif st.velocity == 0:
+            if key not in st.active:
+                raise ValueError("off")
+            on, v = st.active.pop(key)
+            _add(st, on, time, value, v, st.program)
+        else:
+            if key in st.active:
+                on, v = st.active.pop(key)
+                _add(st, on, time, value, v, st.program)
+            st.active[key] = (time, st.velocity)
+    elif etype == "drum":
+        if st.velocity == 0:
+            raise ValueError("drum")
+        _add(st, time, time + DEFAULT_NOTE_DURATION, value, st.velocity, is_drum=True)
+    elif etype == "velocity":
+        lo, hi = type_range("velocity", ranges)
+        bins = hi - lo
+        st.velocity = 0 if value == 0 else int(127 * value / bins)
+    elif etype == "program":
+        st.program = value
+    elif etype == "tie":
+        if not st.tie_section:
+            raise ValueError("tie end")
+        for key in list(st.active.keys()):
+            if key not in st.tied:
+                on, v = st.active.pop(key)
+                _add(st, on, st.current_time, key[0], v, key[1])
+        st.tie_section = False
+    else:
+        raise ValueError(etype)
+
+
+def decode_events(st, tokens, start_time, max_time, ranges=RANGES_V1):
+    invalid = dropped = 0
+    cur_steps, cur_time = 0, start_time
+    for idx, tok in enumerate(tokens):
+        try:
+            etype, value = decode_index(int(tok), ranges)
+        except ValueError:
+            invalid += 1
+            continue
+        if etype == "shift":
+            cur_steps += value
+            cur_time = start_time + cur_steps / STEPS_PER_SECOND
+            if max_time and cur_time > max_time:
+                dropped = len(tokens) - idx
+                break
+        else:
+            cur_steps = 0
+            try:
+                decode_note_event(st, cur_time, etype, value, ranges)
+            except ValueError:
+                invalid += 1
+    return invalid, dropped
+
+
+def flush(st):
+    for on, _ in st.active.values():
+        st.current_time = max(st.current_time, on + MIN_NOTE_DURATION)
+    for key in list(st.active.keys()):
+        on, v = st.active.pop(key)
+        _add(st, on, st.current_time, key[0], v, key[1])
+    prog_inst = {}
+    for n in st.notes:
+        if n[4] not in prog_inst and not n[5]:
+            k = len(prog_inst)
+            n[6] = k if k < 9 else k + 1
+            prog_inst[n[4]] = n[6]
+        elif n[5]:
+            n[6] = 9
+        else:
+            n[6] = prog_inst[n[4]]
+    return st.notes
+
+
+def predictions_to_notes(predictions):
+    """metrics_utils.decode_and_combine_predictions with NoteEncodingWithTiesSpec."""
+    preds = sorted(predictions, key=lambda p: p["start_time"])
+    st = State()
+    inv = drp = 0
+    for i, p in enumerate(preds):
+        st.tied, st.tie_section = set(), True
+        limit = preds[i + 1]["start_time"] if i < len(preds) - 1 else None
+        a, b = decode_events(st, p["est_tokens"], p["start_time"], limit)
+        inv += a
+        drp += b
+    return flush(st), inv, drp
+
+
+def to_event(predictions_np, frame_times):
+    """inference.py:217-234."""
+    preds = []
+    for i, batch in enumerate(predictions_np):
+        for j, tokens in enumerate(batch):
+            tokens = tokens[:np.argmax(tokens == -1)]
+            start = frame_times[i][j][0]
+            start -= start % (1 / STEPS_PER_SECOND)
+            preds.append({"est_tokens": tokens, "start_time": start})
+    return predictions_to_notes(preds)

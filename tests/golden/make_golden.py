@@ -171,5 +171,25 @@ def main():
     print("wrote", os.path.join(HERE, "model_golden.npz"), {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def codec_golden():
+    """contrib/event_codec.py has no third-party imports: record its tables directly."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ref_event_codec", "/root/reference/contrib/event_codec.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    ranges = [m.EventRange('pitch', 0, 127), m.EventRange('velocity', 0, 1), m.EventRange('tie', 0, 0),
+              m.EventRange('program', 0, 127), m.EventRange('drum', 0, 127)]     # vocabularies.py:118-139, bins=1
+    c = m.Codec(max_shift_steps=1000, steps_per_second=100, event_ranges=ranges)
+    idx = [0, 1, 999, 1000, 1001, 1060, 1128, 1129, 1130, 1131, 1132, 1200, 1259, 1260, 1300, 1387]
+    out = {"num_classes": c.num_classes, "max_shift_steps": c.max_shift_steps,
+           "decode": {str(i): [c.decode_event_index(i).type, c.decode_event_index(i).value] for i in idx},
+           "ranges": {t: list(c.event_type_range(t)) for t in ("shift", "pitch", "velocity", "tie", "program", "drum")},
+           "encode": {f"{t}:{v}": c.encode_event(m.Event(t, v)) for t, v in
+                      (("shift", 7), ("pitch", 60), ("velocity", 1), ("tie", 0), ("program", 33), ("drum", 36))}}
+    json.dump(out, open(os.path.join(HERE, "codec_golden.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    codec_golden()
     main()

@@ -93,8 +93,18 @@ def test_inference_handler_matches_oracle_pipeline(dev):
     assert pads == [256, 57] and np.array_equal(ft, ft_ref)
     np.testing.assert_allclose(mel_dev.cpu().numpy(), mel_ref, atol=1e-4, rtol=0)
     assert (mel_dev[1, 57:] == 0).all()
-    results, _ = h.inference(audio, batch_size=8, max_length=24)
+    results, _ = h.inference(audio, batch_size=8, max_length=24, return_tokens=True)
     sd = {k: torch.from_numpy(v) for k, v in golden_weights(T5_SMALL).items()}
     with torch.no_grad():
         ref_ids = t5_ref.generate_t5(sd, T5_SMALL, torch.from_numpy(mel_ref.astype(np.float32)), max_length=24)
     np.testing.assert_array_equal(results[0], logmel_ref.postprocess_batch(ref_ids.numpy()))
+    # audio -> MIDI file end to end (random weights: the notes are meaningless, the plumbing is what is checked)
+    import os
+    import tempfile
+    from oracle import notes_ref
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "out", "song.mid")
+        ns = h.inference(audio, outpath=out, batch_size=8, max_length=24)
+        assert open(out, "rb").read(4) == b"MThd"
+    ref_notes, _, _ = notes_ref.to_event(results, [ft])
+    assert [[n.start_time, n.end_time, n.pitch, n.velocity, n.program, n.is_drum, n.instrument] for n in ns.notes] == ref_notes
