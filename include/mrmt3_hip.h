@@ -204,12 +204,19 @@ void mrmt3_decoder_destroy(mrmt3_decoder* dec);
 int mrmt3_decoder_begin(mrmt3_decoder* dec, const mrmt3_decoder_weights* w, const void* cross_kv,
                         int batch, int enc_len, int64_t* tokens_out, int start_id, int eos_id,
                         int pad_id, void* stream);
+/* Optional, after mrmt3_decoder_begin: feed n_prefix caller-owned f32 rows per batch row
+ * (prefix [batch][n_prefix][d_model], WITHOUT the positional term) as decoder positions
+ * 0..n_prefix-1 before the start token, which moves to position n_prefix.  This is
+ * T5SegMem.generate_2's memory-prefixed decoder input (models/t5_segmem.py:198-213): the first
+ * n_prefix steps of mrmt3_decoder_run only fill the self-attention cache, token steps follow.
+ * Needs n_prefix + token steps <= max_len.  mrmt3_decoder_begin clears the prefix. */
+int mrmt3_decoder_set_prefix(mrmt3_decoder* dec, const float* prefix, int n_prefix, void* stream);
 /* Run n_steps decode steps (graph replays; captured on first use).  No host synchronisation. */
 int mrmt3_decoder_run(mrmt3_decoder* dec, int n_steps, void* stream);
 /* 1 if the current configuration is being replayed from a captured hipGraph (0 = plain launches). */
 int mrmt3_decoder_graph_captured(const mrmt3_decoder* dec);
 /* state_out[0] = steps taken so far, [1] = 1 if every row has emitted EOS, [2] = step index at
- * which the last row finished (or -1).  Copies 3 int32 asynchronously to caller-owned PINNED host
+ * which the last row finished (or -1); [0] counts prefix positions too, [2] counts token steps only.  Copies 3 int32 asynchronously to caller-owned PINNED host
  * memory; the caller synchronises the stream before reading. */
 int mrmt3_decoder_poll(mrmt3_decoder* dec, int32_t* state_out_pinned, void* stream);
 

@@ -47,6 +47,7 @@ __device__ __forceinline__ float gelu_new_d(float x) {
 #define ST_T 0
 #define ST_ALL 1
 #define ST_FIN 2
+#define ST_NPRE 3   // number of prefix (memory) positions fed before the start token
 #define ST_FLAGS 4
 
 // ---- norm + gemv: every WAVE normalises x[b] for itself from registers (8 elements per lane, one
@@ -236,12 +237,28 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
 // argmax + EOS bookkeeping (models/t5.py:286-295) + embedding of the next token; single workgroup
 __global__ __launch_bounds__(256) void dec_argmax(const float* __restrict__ logits, int V, int B, int64_t* __restrict__ tokens,
                                                   int tok_ld, const float* __restrict__ embed, const float* __restrict__ pos,
-                                                  float* __restrict__ x, int* __restrict__ state, int eos, int pad) {
+                                                  float* __restrict__ x, int* __restrict__ state, int eos, int pad,
+                                                  const float* __restrict__ prefix) {
   __shared__ float bv[4];
   __shared__ int bi[4];
   __shared__ int nxt_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = state[ST_T];
+  const int p = state[ST_T];            // position just processed
+  const int npre = state[ST_NPRE];
+  if (p + 1 <= npre) {
+    // still inside the prefix: the next input is the next memory row, or the start token right after
+    // the last one (models/t5_segmem.py:203-213); this step's logits are discarded
+    for (int b = 0; b < B; ++b) {
+      const float* er = (p + 1 < npre) ? prefix + ((size_t)b * npre + p + 1) * DMODEL
+                                       : embed + (size_t)tokens[(size_t)b * tok_ld] * DMODEL;
+      const float* pr = pos + (size_t)(p + 1) * DMODEL;
+      x[b * DMODEL + tid] = er[tid] + pr[tid];
+      x[b * DMODEL + 256 + tid] = er[256 + tid] + pr[256 + tid];
+    }
+    if (tid == 0) state[ST_T] = p + 1;
+    return;
+  }
+  const int t = p - npre;               // token step
   int all_done = 1;
   for (int b = 0; b < B; ++b) {
     float best = -INFINITY;
@@ -271,14 +288,25 @@ __global__ __launch_bounds__(256) void dec_argmax(const float* __restrict__ logi
     const int nxt = nxt_s;
     all_done &= state[ST_FLAGS + b];
     const float* er = embed + (size_t)nxt * DMODEL;
-    const float* pr = pos + (size_t)(t + 1) * DMODEL;
+    const float* pr = pos + (size_t)(p + 1) * DMODEL;
     x[b * DMODEL + tid] = er[tid] + pr[tid];
     x[b * DMODEL + 256 + tid] = er[256 + tid] + pr[256 + tid];
     __syncthreads();
   }
   if (tid == 0) {
     if (all_done && !state[ST_ALL]) { state[ST_ALL] = 1; state[ST_FIN] = t; }
-    state[ST_T] = t + 1;
+    state[ST_T] = p + 1;
+  }
+}
+
+// position 0 becomes the first memory row instead of the start token
+__global__ void dec_prefix_kernel(int B, int n_prefix, const float* prefix, const float* pos, float* x, int* state) {
+  const int tid = threadIdx.x;
+  if (tid == 0) state[ST_NPRE] = n_prefix;
+  for (int b = 0; b < B; ++b) {
+    const float* er = prefix + (size_t)b * n_prefix * DMODEL;
+    x[b * DMODEL + tid] = er[tid] + pos[tid];
+    x[b * DMODEL + 256 + tid] = er[256 + tid] + pos[256 + tid];
   }
 }
 
@@ -305,6 +333,7 @@ struct mrmt3_decoder {
   const void *ln_self[64], *w_qkv[64], *w_o_self[64], *ln_cross[64], *w_q_cross[64], *w_o_cross[64], *ln_ff[64],
       *w_wi[64], *w_wo[64];
   const void* cross_kv;
+  const float* prefix;   // [B][n_prefix][d] f32 memory rows fed before the start token (or null)
   int B, encLen, eos, pad;
   int64_t* tokens;
   hipGraph_t graph;
@@ -378,6 +407,16 @@ extern "C" int mrmt3_decoder_begin(mrmt3_decoder* D, const mrmt3_decoder_weights
   return MRMT3_OK;
 }
 
+extern "C" int mrmt3_decoder_set_prefix(mrmt3_decoder* D, const float* prefix, int n_prefix, void* stream) {
+  MR_CHECK_ARG(D && D->tokens, "decoder_set_prefix: call decoder_begin first");
+  MR_CHECK_ARG(prefix && n_prefix > 0 && n_prefix < D->maxLen, "decoder_set_prefix: need 0 < n_prefix < max_len rows");
+  if (D->prefix != prefix) { D->prefix = prefix; D->captured = 0; }   // pointer is baked into the graph
+  hipLaunchKernelGGL(dec_prefix_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, D->B, n_prefix, prefix, D->w.pos,
+                     D->x, D->state);
+  MR_CHECK_LAUNCH("decoder_set_prefix");
+  return MRMT3_OK;
+}
+
 template <typename TW, int NB>
 static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   const int B = D->B, inner = D->inner, dff = D->dff, V = D->V;
@@ -416,7 +455,7 @@ static int launch_step(mrmt3_decoder* D, hipStream_t s) {
                      (const TW*)D->w.lm_head, V, D->eps, D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
                      D->state);
   hipLaunchKernelGGL(dec_argmax, dim3(1), dim3(256), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
-                     (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad);
+                     (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad, D->prefix);
   MR_CHECK_LAUNCH("decoder step");
   return MRMT3_OK;
 }

@@ -87,6 +87,9 @@ class GradBuckets:
         assert pos == flat.numel
         self._works = []
         self._fired = set()
+        # called right before a bucket's all-reduce is enqueued; the engine hooks its side-stream join
+        # here (weight gradients are produced on a second stream, see Engine.wgrad)
+        self.before_fire = None
 
     def reset(self):
         self._works, self._fired = [], set()
@@ -98,6 +101,8 @@ class GradBuckets:
         if self.world == 1:
             return
         b = self.buckets[idx]
+        if self.before_fire is not None:
+            self.before_fire()
         self._works.append(dist.all_reduce(self.flat.G[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.group,
                                            async_op=True))
 

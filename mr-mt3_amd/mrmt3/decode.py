@@ -94,9 +94,9 @@ class Decoder:
             lib.gemm_nt(enc_cat, eng.W(f"decoder.{i}.ckv"), out=out[i])
         return out
 
-    def run(self, ckv, B, Lc, max_steps, poll_every=64):
+    def run(self, ckv, B, Lc, max_steps, poll_every=64, prefix=None):
         """Decode up to max_steps tokens for B rows; returns (tokens [B, max_len+1] view, steps run,
-        finish_step or -1)."""
+        finish_step or -1).  `prefix` [B, n, d] f32: memory rows fed as decoder positions 0..n-1."""
         cfg = self.model.cfg
         l = lib.load()
         w = self._weights()
@@ -104,14 +104,21 @@ class Decoder:
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            out = self._run_on_stream(l, w, ckv, B, Lc, max_steps, poll_every, cfg)
+            out = self._run_on_stream(l, w, ckv, B, Lc, max_steps, poll_every, cfg, prefix)
         cur.wait_stream(self.stream)
         return out
 
-    def _run_on_stream(self, l, w, ckv, B, Lc, max_steps, poll_every, cfg):
+    def _run_on_stream(self, l, w, ckv, B, Lc, max_steps, poll_every, cfg, prefix=None):
         lib._check(l.mrmt3_decoder_begin(self.h, C.byref(w), lib._p(ckv), B, Lc, lib._p(self.tokens),
                                          cfg["decoder_start_token_id"], cfg["eos_token_id"], cfg["pad_token_id"],
                                          lib._stream()), "decoder_begin")
+        if prefix is not None:
+            n_pre = prefix.shape[1]
+            assert prefix.dtype == torch.float32 and prefix.is_contiguous() and prefix.shape[0] == B
+            assert n_pre + max_steps <= self.max_len, "prefix + token steps exceed the decoder's max_len"
+            self._prefix = prefix        # keep alive while the graph may read it
+            lib._check(l.mrmt3_decoder_set_prefix(self.h, lib._p(prefix), n_pre, lib._stream()), "decoder_set_prefix")
+            max_steps += n_pre
         done, fin = 0, -1
         while done < max_steps:
             n = min(poll_every, max_steps - done)
@@ -146,7 +153,7 @@ def generate(model, inputs, max_length=1024, poll_every=64):
     eng.prepare(False)
     B, Le, d = inputs.shape
     enc = eng.encode(inputs.float() if inputs.dtype not in (torch.float32, torch.bfloat16) else inputs)
-    if model.VARIANT == "t5":
+    if model.VARIANT in ("t5", "segmem_v1"):      # T5SegMem.generate ignores the memory (t5_segmem.py:254-311)
         out = []
         for b0 in range(0, B, 8):   # the step kernels batch up to 8 rows
             nb = min(8, B - b0)
@@ -166,7 +173,7 @@ def generate(model, inputs, max_length=1024, poll_every=64):
             r += t.shape[0]
         return res
     if model.VARIANT == "segmem_v1":
-        raise NotImplementedError("T5SegMem (V1) has no `generate` in the reference either (only generate_2)")
+        raise RuntimeError("T5SegMem.generate is the plain batched decode; memory decode is generate_2")
     # segment-memory models: sequential segments, memory = previous segment's tokens
     Ls = min(model.segmem_length, max_length)            # `[:, :segmem_length]` of a max_length-long sequence
     seg_ids = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
@@ -184,6 +191,41 @@ def generate(model, inputs, max_length=1024, poll_every=64):
         steps = (fin + 1) if fin >= 0 else max_length
         row = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
         n = min(steps + 1, max_length)                   # F.pad(..., max_length - len) truncates (:287-291)
+        row[0, :n] = toks[0, :n]
+        outs.append(row)
+        seg_ids = row
+    return torch.cat(outs, 0)
+
+
+@torch.no_grad()
+def generate_2(model, inputs, max_length=1024, poll_every=64):
+    """`T5SegMem.generate_2` (models/t5_segmem.py:172-252): segments one after the other; the previous
+    segment's tokens go through the segment-memory encoder and its first `segmem_length` outputs are
+    PREPENDED to the decoder's input embeddings.  With the KV cache that is a prefix fill: the memory
+    rows are fed as decoder positions 0..Ls-1 (self-attention K/V only), tokens start at position Ls.
+    A stable prefix buffer keeps the captured step graph valid across segments."""
+    eng, cfg = model.engine, model.cfg
+    if not inputs.is_cuda:
+        raise RuntimeError("generate_2 needs device tensors (no CPU fallback)")
+    Ls = model.segmem_length
+    assert max_length >= Ls, "the reference asserts segmem_length memory rows (t5_segmem.py:213)"
+    eng.prepare(False)
+    B, Le, d = inputs.shape
+    enc = eng.encode(inputs)
+    seg_ids = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
+    seg_ids[0, 0] = 1                                          # t5_segmem.py:190-196
+    dec = _decoder_for(model, 1, max_length + Ls, Le)
+    pre = getattr(dec, "_prefix_buf", None)
+    if pre is None or pre.shape[1] != Ls:
+        pre = dec._prefix_buf = torch.empty(1, Ls, d, device=inputs.device, dtype=torch.float32)
+    outs = []
+    for i in range(B):
+        pre.copy_(eng.segmem(seg_ids, 1, max_length).float().view(1, Ls, d))
+        ckv = dec.cross_kv(enc.view(B, Le, d)[i].contiguous(), 1, Le)
+        toks, done, fin = dec.run(ckv, 1, Le, max_length, poll_every, prefix=pre)
+        steps = (fin + 1) if fin >= 0 else max_length
+        row = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
+        n = min(steps + 1, max_length)
         row[0, :n] = toks[0, :n]
         outs.append(row)
         seg_ids = row

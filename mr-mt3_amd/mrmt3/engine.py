@@ -15,6 +15,8 @@ the row for three reference ops (`hidden + dropout(sublayer)`, then `T5LayerNorm
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import lib
@@ -52,6 +54,11 @@ class Engine:
         # dtype of sublayer outputs / dgrad outputs entering the fp32 residual add: the compute dtype
         # (bf16 halves that stream's HBM traffic; the residual itself and all statistics stay fp32)
         self.y_dtype = compute_dtype
+        # weight-gradient GEMMs are off the critical dgrad chain: they run on a second HIP stream and
+        # overlap the attention / dgrad kernels of the layers below (their outputs are only needed by
+        # the optimizer / the gradient exchange)
+        self.overlap_wgrad = os.environ.get("MRMT3_WGRAD_STREAM", "1") != "0"
+        self._side = None
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def pos(self, device):
@@ -68,6 +75,27 @@ class Engine:
 
     def ln(self, key):
         return self.flat.master(key)
+
+    def side_stream(self):
+        if self._side is None or self._side.device != torch.cuda.current_stream().device:
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("MRMT3_WGRAD_PRIO", "0")))
+        return self._side
+
+    def wgrad(self, a, b, out):
+        """out += a^T @ b on the side stream (inputs were produced on the current stream)."""
+        if not self.overlap_wgrad:
+            return lib.gemm_tn(a, b, out, accumulate=True)
+        side = self.side_stream()
+        side.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(side):
+            lib.gemm_tn(a, b, out, accumulate=True)
+        a.record_stream(side)
+        b.record_stream(side)
+
+    def join_wgrad(self):
+        """Make the current stream wait for every weight gradient issued so far."""
+        if self.overlap_wgrad and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def prepare(self, training: bool):
         if self.dt == torch.bfloat16:
@@ -153,10 +181,10 @@ class Engine:
             t = tape.pop()
             assert t["kind"] == "ff" and t["i"] == i
             ff = t["ff"]
-            lib.gemm_tn(dy, t["g"], f.GW(f"{prefix}.{i}.wo"), accumulate=True)
+            self.wgrad(dy, t["g"], f.GW(f"{prefix}.{i}.wo"))
             dg = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.wo"))
             dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, stream_id=t["s_g"])
-            lib.gemm_tn(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"), accumulate=True)
+            self.wgrad(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"))
             dxn = lib.gemm_nt(dh, f.WT(f"{prefix}.{i}.wi"), out_dtype=self.y_dtype)
             dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
                                          f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
@@ -164,15 +192,15 @@ class Engine:
             if ff == 2:
                 t = tape.pop()
                 assert t["kind"] == "cross"
-                lib.gemm_tn(dy, t["o"], f.GW(f"{prefix}.{i}.co"), accumulate=True)
+                self.wgrad(dy, t["o"], f.GW(f"{prefix}.{i}.co"))
                 do = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.co"))
                 dq = torch.empty_like(t["q"])
                 dkv = torch.empty_like(t["kv"])
                 kv = t["kv"]
                 lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
                              dkv[:, inner:], B, H, L, Le, False, p=p, seed=seed, stream_id=t["s_att"])
-                lib.gemm_tn(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"), accumulate=True)
-                lib.gemm_tn(dkv, enc, f.GW(f"{prefix}.{i}.ckv"), accumulate=True)
+                self.wgrad(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"))
+                self.wgrad(dkv, enc, f.GW(f"{prefix}.{i}.ckv"))
                 lib.gemm_nt(dkv, f.WT(f"{prefix}.{i}.ckv"), out=d_enc, accumulate=True)
                 dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
                 dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
@@ -180,14 +208,14 @@ class Engine:
                                              dx1=dx)
             t = tape.pop()
             assert t["kind"] == "self" and t["i"] == i
-            lib.gemm_tn(dy, t["o"], f.GW(f"{prefix}.{i}.o"), accumulate=True)
+            self.wgrad(dy, t["o"], f.GW(f"{prefix}.{i}.o"))
             do = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.o"))
             qkv = t["qkv"]
             dqkv = torch.empty_like(qkv)
             lib.attn_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], t["o"], do, t["lse"],
                          dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, H, L, L, is_dec, p=p,
                          seed=seed, stream_id=t["s_att"])
-            lib.gemm_tn(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"), accumulate=True)
+            self.wgrad(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"))
             dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
             dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
                                          f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed,
@@ -222,7 +250,7 @@ class Engine:
         t = tape.pop()
         assert t["kind"] == "enc_in"
         dsrc = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, stream_id=t["s_emb"])
-        lib.gemm_tn(dsrc, t["mel"], self.flat.GW("proj"), accumulate=True)
+        self.wgrad(dsrc, t["mel"], self.flat.GW("proj"))
 
     def segmem(self, ids, B, L, tape=None):
         """embed -> segmem_proj -> 1-layer bidirectional encoder, dropout 0
@@ -284,21 +312,21 @@ class Engine:
             d_out = d_mem.contiguous().view(B * Ls, d)
             dx2, dy2 = lib.add_rmsnorm_bwd(d_out, None, t["x2"], t["rstd2"], self.ln(f"{pre}.final_layer_norm.weight"),
                                            f.grad(f"{pre}.final_layer_norm.weight"))
-            lib.gemm_tn(dy2, t["g"], f.GW(f"{pre}.0.wo"), accumulate=True)
+            self.wgrad(dy2, t["g"], f.GW(f"{pre}.0.wo"))
             dg = lib.gemm_nt(dy2, f.WT(f"{pre}.0.wo"))
             dh = lib.geglu_bwd(t["h"], dg)
-            lib.gemm_tn(dh, t["xn1"], f.GW(f"{pre}.0.wi"), accumulate=True)
+            self.wgrad(dh, t["xn1"], f.GW(f"{pre}.0.wi"))
             dxn1 = lib.gemm_nt(dh, f.WT(f"{pre}.0.wi"), out_dtype=self.y_dtype)
             dx1, dy = lib.add_rmsnorm_bwd(dxn1, dx2, t["x1"], t["rstd1"], self.ln(f"{b}.1.layer_norm.weight"),
                                           f.grad(f"{b}.1.layer_norm.weight"), dx1=dx2)
-            lib.gemm_tn(dy, t["o"], f.GW(f"{pre}.0.o"), accumulate=True)
+            self.wgrad(dy, t["o"], f.GW(f"{pre}.0.o"))
             do = lib.gemm_nt(dy, f.WT(f"{pre}.0.o"))
             kv = t["kv"]
             dq, dkv = torch.empty_like(t["q"]), torch.empty_like(kv)
             lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
                          dkv[:, inner:], B, H, Ls, L, False)
-            lib.gemm_tn(dq, t["xns"], GW[:inner], accumulate=True)
-            lib.gemm_tn(dkv, t["xn_full"], GW[inner:], accumulate=True)
+            self.wgrad(dq, t["xns"], GW[:inner])
+            self.wgrad(dkv, t["xn_full"], GW[inner:])
             dxn_full = lib.gemm_nt(dkv, WT[:, inner:], out_dtype=torch.float32)          # [B*L, d]
             dxns = lib.gemm_nt(dq, WT[:, :inner], out_dtype=torch.float32)               # [B*Ls, d]
             dxn_full.view(B, L, d)[:, :Ls] += dxns.view(B, Ls, d)
@@ -309,7 +337,7 @@ class Engine:
                                         want_dy=False)
         assert t["kind"] == "seg_in"
         dsrc = lib.dropmask_cast(dx)
-        lib.gemm_tn(dsrc, t["emb"], f.GW("segmem_proj"), accumulate=True)
+        self.wgrad(dsrc, t["emb"], f.GW("segmem_proj"))
         demb = lib.gemm_nt(dsrc, f.WT("segmem_proj"), out_dtype=torch.float32)
         lib.embed_bwd(t["ids"], demb, f.grad("decoder_embed_tokens.weight"), t["L"], shift=False,
                       pad_id=self.cfg["pad_token_id"])
@@ -393,7 +421,7 @@ class Engine:
         dl = dlogits.reshape(-1, self.V)
         if dl.dtype != torch.bfloat16:
             dl = self._act(dl)
-        lib.gemm_tn(dl, t["dec"], f.GW("lm_head"), accumulate=True)
+        self.wgrad(dl, t["dec"], f.GW("lm_head"))
         d_dec = lib.gemm_nt(dl, f.WT("lm_head"), out_dtype=torch.float32)
         if on_layer_done is not None:
             on_layer_done("lm_head", 0)
@@ -429,4 +457,5 @@ class Engine:
         if d_mem is not None:
             self.segmem_bwd(tape, d_mem)
         self.encode_bwd(tape, d_enc, on_layer_done=on_layer_done)
+        self.join_wgrad()
         assert not tape.ops, [o["kind"] for o in tape.ops]

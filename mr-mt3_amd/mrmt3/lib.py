@@ -50,6 +50,7 @@ _SIGS = {
     "mrmt3_decoder_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci, ci, ci, cf]),
     "mrmt3_decoder_destroy": (None, [vp]),
     "mrmt3_decoder_begin": (ci, [vp, vp, vp, ci, ci, vp, ci, ci, ci, vp]),
+    "mrmt3_decoder_set_prefix": (ci, [vp, vp, ci, vp]),
     "mrmt3_decoder_graph_captured": (ci, [vp]),
     "mrmt3_decoder_run": (ci, [vp, ci, vp]),
     "mrmt3_decoder_poll": (ci, [vp, vp, vp]),
@@ -176,7 +177,8 @@ _ws_cache = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    key = (device.index if hasattr(device, "index") else 0)
+    # one scratch buffer per (device, stream): kernels on different streams may run concurrently
+    key = (device.index if hasattr(device, "index") else 0, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

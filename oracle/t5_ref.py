@@ -252,6 +252,40 @@ def generate_segmem_v2(sd, cfg, mel, max_length=1024, segmem_length=64, with_pre
     return (out, margins) if return_margins else out
 
 
+def generate_segmem_v1(sd, cfg, mel, max_length=1024, segmem_length=64, return_margins=False):
+    """`T5SegMem.generate_2` (`models/t5_segmem.py:172-252`): per segment, the memory (previous segment's
+    tokens through segmem_proj + segmem_encoder, first `segmem_length` positions) is PREPENDED to the
+    decoder input embeddings; the decoder runs causally over [memory ; tokens] and the memory positions
+    are sliced off before lm_head.  First segment's memory ids are [1,0,0,...] (`:190-196`)."""
+    enc = encode(sd, cfg, mel)
+    table = sd["decoder_embed_tokens.weight"]
+    outs, margins = [], []
+    seg_ids = torch.zeros(1, max_length, dtype=torch.long)
+    seg_ids[0, 0] = 1
+    for i in range(enc.shape[0]):
+        mem = segmem_memory(sd, cfg, seg_ids, segmem_length)
+        Ls = mem.shape[1]
+        toks = torch.zeros(1, 1, dtype=torch.long)
+        m = []
+        for _ in range(max_length):
+            emb = torch.cat([mem, table[toks]], dim=1)
+            y = decode_logits(sd, cfg, None, enc[i:i + 1], dec_embeds=emb)[:, Ls:]
+            logits = y[:, -1] @ sd["lm_head.weight"].t()
+            if return_margins:
+                top2 = logits.topk(2, dim=-1).values
+                m.append(float(top2[0, 0] - top2[0, 1]))
+            nxt = logits.argmax(-1)
+            toks = torch.cat([toks, nxt[:, None]], dim=1)
+            if int(nxt) == cfg["eos_token_id"]:
+                break
+        toks = F.pad(toks, (0, max_length - toks.shape[1]), value=0)     # negative pad truncates (:240-244)
+        outs.append(toks)
+        margins.append(m)
+        seg_ids = toks
+    out = torch.cat(outs, dim=0)
+    return (out, margins) if return_margins else out
+
+
 def cosine_lambda(step, num_warmup_steps, num_training_steps, num_cycles=0.5, min_lr=2e-5):
     """`utils.py:53-61`: note `min_lr` floors the LambdaLR *multiplier*."""
     if step < num_warmup_steps:

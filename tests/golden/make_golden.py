@@ -80,6 +80,9 @@ def install_shim():
 
 
 def build_reference(variant: str, segmem_length: int = 64):
+    # the drop-in tree has same-named packages (`models`, `tasks`, ...): take it off the path so that
+    # `models.*` can only resolve to the reference (checked below)
+    sys.path[:] = [p for p in sys.path if not p.rstrip("/").endswith("mr-mt3_amd")]
     sys.path.insert(0, "/root/reference")
     from transformers import T5Config
     cfg = dict(T5_SMALL)
@@ -102,6 +105,7 @@ def build_reference(variant: str, segmem_length: int = 64):
         M = getattr(importlib.import_module(mod[0]), mod[1])
         m = M(tc, segmem_num_layers=1, segmem_length=segmem_length)
         seg_layers = 1
+    assert sys.modules[M.__module__].__file__.startswith("/root/reference/"), sys.modules[M.__module__].__file__
     w = golden_weights(T5_SMALL, seg_layers)
     sd = {k: torch.from_numpy(v) for k, v in w.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -124,6 +128,8 @@ def sample_idx(shape, n, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true")
+    ap.add_argument("--v1-decode", action="store_true",
+                    help="only add T5SegMem's generate / generate_2 outputs to the existing npz")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -135,6 +141,20 @@ def main():
     lab_pad = torch.from_numpy(synth_labels(B, full=False, seed=777))
     prev = torch.from_numpy(synth_labels(B, full=False, seed=999))
     import torch.nn.functional as F
+
+    if args.v1_decode:
+        import contextlib, io
+        path = os.path.join(HERE, "model_golden.npz")
+        out = dict(np.load(path))
+        m = build_reference("segmem_v1")
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):   # the reference prints every step
+            for ml in (32, 256):
+                out[f"segmem_v1.gen{ml}"] = m.generate(inputs=mel, max_length=ml).numpy().astype(np.int16)
+            for ml in (96, 256):     # generate_2 asserts max_length >= segmem_length (t5_segmem.py:213)
+                out[f"segmem_v1.gen2_{ml}"] = m.generate_2(inputs=mel, max_length=ml).numpy().astype(np.int16)
+        np.savez_compressed(path, **out)
+        print("added", [k for k in out if k.startswith("segmem_v1.gen")])
+        return
 
     for variant in ("t5", "segmem_v1", "segmem_v2", "segmem_v2_with_prev"):
         t0 = time.time()

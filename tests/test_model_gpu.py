@@ -182,6 +182,36 @@ def test_greedy_segmem_token_ids_bit_exact_fp32(dev, golden, variant, ml):
     np.testing.assert_array_equal(ids.cpu().numpy(), golden[f"{variant}.gen{ml}"])
 
 
+@pytest.mark.parametrize("ml", [96, 256])
+def test_greedy_segmem_v1_generate_2_bit_exact_fp32(dev, golden, ml):
+    """T5SegMem.generate_2: memory rows prefill the self-attention cache, tokens start at position 64."""
+    m = _build("segmem_v1", torch.float32, dev)
+    mel = _inputs(dev)[0]
+    ids = m.generate_2(mel, max_length=ml)
+    assert ids.shape == (2, ml) and m._decoder.graph_captured
+    np.testing.assert_array_equal(ids.cpu().numpy(), golden[f"segmem_v1.gen2_{ml}"])
+    # and the plain batched decode of the same class
+    np.testing.assert_array_equal(m.generate(mel, max_length=32).cpu().numpy(), golden["segmem_v1.gen32"])
+
+
+def test_segmem_v1_generate_2_early_eos_matches_oracle(dev):
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel
+    from oracle import t5_ref
+    w = golden_weights(T5_SMALL, 1)
+    w["lm_head.weight"] = w["lm_head.weight"].copy()
+    w["lm_head.weight"][1] *= 3.2
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    mel = torch.from_numpy(synth_mel(3, seed=11))
+    with torch.no_grad():
+        ref = t5_ref.generate_segmem_v1(sd, T5_SMALL, mel, max_length=100)
+    m = _build("segmem_v1", torch.float32, dev)
+    with torch.no_grad():
+        m.flat.load_numpy(w)
+    ids = m.generate_2(mel.to(dev), max_length=100)
+    assert (ref == 1).any(), "EOS never fired; raise the boost"
+    assert torch.equal(ids.cpu(), ref)
+
+
 def test_greedy_eos_handling_matches_oracle(dev):
     """Force early EOS: rows finish at different steps, later tokens are pad, loop stops early."""
     from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel

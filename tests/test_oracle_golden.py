@@ -47,6 +47,16 @@ def test_greedy_t5_matches_reference(golden):
     np.testing.assert_array_equal(ids.numpy(), golden["t5.gen32"])
 
 
+def test_greedy_segmem_v1_matches_reference(golden):
+    """T5SegMem.generate (plain batched decode) and generate_2 (memory prepended to the decoder input)."""
+    mel = torch.from_numpy(synth_mel(2))
+    with torch.no_grad():
+        ids = t5_ref.generate_t5(_sd("segmem_v1"), T5_SMALL, mel, max_length=32)
+        ids2 = t5_ref.generate_segmem_v1(_sd("segmem_v1"), T5_SMALL, mel, max_length=96)
+    np.testing.assert_array_equal(ids.numpy(), golden["segmem_v1.gen32"])
+    np.testing.assert_array_equal(ids2.numpy(), golden["segmem_v1.gen2_96"])
+
+
 @pytest.mark.parametrize("variant", ["segmem_v2", "segmem_v2_with_prev"])
 def test_greedy_segmem_matches_reference(golden, variant):
     mel = torch.from_numpy(synth_mel(2))
