@@ -70,6 +70,40 @@ class Trainer:
         self.last_loss = loss
         return loss
 
+    # ---- checkpoint / resume (Lightning `.ckpt` layout, see mrmt3.checkpoint) -------------------------------
+    def save_checkpoint(self, path: str, epoch: int = 0):
+        """Write weights + AdamW moments + step in the layout the reference's ModelCheckpoint produces, so
+        either side can resume from it (`train.py:61-72`).  `.pt` / `.pth` paths get the bare state dict
+        (`train.py:105-116`)."""
+        from . import checkpoint as ck
+        torch.cuda.current_stream().synchronize()
+        if str(path).endswith(".ckpt"):
+            torch.save(ck.lightning_checkpoint(self.model, self, epoch), path)
+        else:
+            torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, path)
+
+    def resume(self, path: str, strict: bool = False) -> int:
+        """Load weights (and, from a `.ckpt`, optimizer moments and the step counter).  Returns the global
+        step training continues from."""
+        from . import checkpoint as ck
+        blob = ck.read_checkpoint(path)
+        self.model.load_state_dict(blob["state_dict"], strict=strict)
+        step = 0
+        if blob["optimizer"] is not None:
+            order = ck.reference_parameter_order(self.model.cfg, self.model.segmem_num_layers)
+            step = ck.adamw_state_to_flat(blob["optimizer"], self.flat, order)
+            step = max(step, blob["global_step"])
+        self.host_step = step
+        self.step_dev.fill_(step)
+        if blob["extra"]:
+            self.engine.seed = int(blob["extra"]["dropout_seed"])
+            self.engine._stream_ctr = int(blob["extra"]["dropout_stream_ctr"])
+        if self.world > 1:
+            dist.broadcast(self.flat.P, src=0)
+            dist.broadcast(self.flat.M, src=0)
+            dist.broadcast(self.flat.V, src=0)
+        return step
+
     @torch.no_grad()
     def eval_loss(self, inputs, labels, targets_prev=None, audio: bool = False):
         self.model.eval()

@@ -37,12 +37,9 @@ except ImportError:  # Lightning absent (as in this image)
 
         @classmethod
         def load_from_checkpoint(cls, path, **kwargs):
-            import torch
-            from utils import remove_state_dict_prefix
+            from mrmt3.checkpoint import read_checkpoint
             obj = cls(**kwargs)
-            ckpt = torch.load(path, map_location="cpu")
-            sd = ckpt.get("state_dict", ckpt)
-            obj.model.load_state_dict(remove_state_dict_prefix(sd), strict=False)
+            obj.model.load_state_dict(read_checkpoint(path)["state_dict"], strict=False)
             return obj
 
 

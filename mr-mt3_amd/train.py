@@ -12,8 +12,13 @@ one process per GPU:
 Real Slakh/ComMU datasets need the reference's `dataset/` package and its third-party stack
 (librosa, note_seq, ...: out of scope); when it is importable the configured
 `cfg.dataset.train._target_` is used as is, otherwise (or with `+synthetic=True`) synthetic
-Slakh-shaped batches exercise the same shapes.  The final weights are exported like
-`train.py:105-116` (bare state dict, no `model.` prefix).
+Slakh-shaped batches exercise the same shapes.
+
+`cfg.path` has the reference's meaning (`train.py:61-92`): a `.ckpt` resumes weights, AdamW moments and
+the step counter; a `.pth` only loads weights (`strict=False`); anything else is an error.  At the end
+rank 0 writes `<output_dir>/<model_type>_<dataset_type>/version_0/checkpoints/last.ckpt` (Lightning
+layout) and `last.pt` (bare state dict, no `model.` prefix) like `train.py:105-116`; `+output_dir=...`
+picks the root (default: the working directory, where Hydra would have put it).
 """
 import argparse
 import os
@@ -69,12 +74,31 @@ def main(argv=None):
                       weighted_loss=type(task).__name__ == "MT3NetWeightedLoss")
     with_prev = "WithPrev" in type(task).__name__
     steps = int(cfg.get("max_steps", 10))
-    for it, (audio, labels, prev) in enumerate(synthetic_batches(cfg, rank, device, steps, with_prev)):
+    start = 0
+    path = cfg.get("path")
+    if path is not None and str(path) != "":
+        path = str(path)
+        if path.endswith(".ckpt"):
+            start = trainer.resume(path)
+            if rank == 0:
+                print(f"Resuming from {path} at step {start}", flush=True)
+        elif path.endswith(".pth"):
+            if rank == 0:
+                print(f"Loading weights from {path}...", flush=True)
+            trainer.resume(path)
+        else:
+            raise ValueError(f"Invalid extension for path: {path}")
+    for it, (audio, labels, prev) in enumerate(synthetic_batches(cfg, rank, device, steps, with_prev), start):
         loss = trainer.train_step(audio, labels, prev, audio=True)
-        if rank == 0 and (it % max(1, int(cfg.trainer.get("log_every_n_steps", 100))) == 0 or it == steps - 1):
+        if rank == 0 and (it % max(1, int(cfg.trainer.get("log_every_n_steps", 100))) == 0 or it == start + steps - 1):
             print(f"step {it} train_loss {loss.item():.4f}", flush=True)
-    if rank == 0 and cfg.get("path"):
-        torch.save(task.model.state_dict(), str(cfg.path))
+    if rank == 0:
+        out_dir = os.path.join(str(cfg.get("output_dir", ".")), f"{cfg.model_type}_{cfg.dataset_type}",
+                               "version_0", "checkpoints")
+        os.makedirs(out_dir, exist_ok=True)
+        trainer.save_checkpoint(os.path.join(out_dir, "last.ckpt"))
+        trainer.save_checkpoint(os.path.join(out_dir, "last.pt"))
+        print(f"Saved model in {os.path.join(out_dir, 'last.pt')}.", flush=True)
     if world > 1:
         dist.destroy_process_group()
     return task

@@ -128,6 +128,8 @@ def sample_idx(shape, n, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true")
+    ap.add_argument("--param-order", action="store_true",
+                    help="only record the reference models' parameters() order (optimizer-state indexing)")
     ap.add_argument("--v1-decode", action="store_true",
                     help="only add T5SegMem's generate / generate_2 outputs to the existing npz")
     args = ap.parse_args()
@@ -142,6 +144,17 @@ def main():
     prev = torch.from_numpy(synth_labels(B, full=False, seed=999))
     import torch.nn.functional as F
 
+    if args.param_order:
+        import json
+        rec = {}
+        for variant in ("t5", "segmem_v1", "segmem_v2", "segmem_v2_with_prev"):
+            m = build_reference(variant)
+            rec[variant] = {"parameters": [n for n, _ in m.named_parameters()],
+                            "state_dict": list(m.state_dict().keys())}
+        with open(os.path.join(HERE, "param_order.json"), "w") as f:
+            json.dump(rec, f, indent=0)
+        print({k: (len(v["parameters"]), len(v["state_dict"])) for k, v in rec.items()})
+        return
     if args.v1_decode:
         import contextlib, io
         path = os.path.join(HERE, "model_golden.npz")

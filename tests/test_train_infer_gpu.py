@@ -108,3 +108,97 @@ def test_inference_handler_matches_oracle_pipeline(dev):
         assert open(out, "rb").read(4) == b"MThd"
     ref_notes, _, _ = notes_ref.to_event(results, [ft])
     assert [[n.start_time, n.end_time, n.pitch, n.velocity, n.program, n.is_drum, n.instrument] for n in ns.notes] == ref_notes
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(dev, tmp_path):
+    """save -> new process-equivalent (fresh model + trainer) -> resume: weights, AdamW moments, step
+    counter, LR schedule position and dropout stream all continue; the next step lands on the same
+    weights up to the atomic-add ordering of the embedding gradient."""
+    from mrmt3 import checkpoint as ck
+    from mrmt3.synthetic import synth_audio, synth_labels
+    from mrmt3.trainer import Trainer
+    from utils import cosine_warmup_lambda
+    lam = cosine_warmup_lambda(4, 100, min_lr=1e-4)
+    audio = [torch.from_numpy(synth_audio(2, seed=s)).to(dev) for s in (1, 2, 3)]
+    labs = [torch.from_numpy(synth_labels(2, 256, full=False, seed=s, mean_len=100)).to(dev) for s in (4, 5, 6)]
+    m = _model("t5", dev)
+    tr = Trainer(m, lr=1e-3, lr_lambda=lam)
+    for i in range(2):
+        tr.train_step(audio[i], labs[i], audio=True)
+    path = str(tmp_path / "last.ckpt")
+    tr.save_checkpoint(path)
+    M2, V2 = m.flat.M.clone(), m.flat.V.clone()
+    loss_a = tr.train_step(audio[2], labs[2], audio=True).item()
+    P_a = m.flat.P.clone()
+
+    blob = torch.load(path, weights_only=False)
+    assert blob["global_step"] == 2 and len(blob["optimizer_states"][0]["state"]) == 189
+    assert all(k.startswith("model.") for k in blob["state_dict"])
+
+    m2 = _model("t5", dev)
+    with torch.no_grad():
+        m2.flat.P.add_(0.01)                      # make sure the weights really come from the file
+    tr2 = Trainer(m2, lr=1e-3, lr_lambda=lam)
+    assert tr2.resume(path) == 2 and int(tr2.step_dev.item()) == 2
+    assert torch.equal(m2.flat.M, M2) and torch.equal(m2.flat.V, V2)
+    loss_b = tr2.train_step(audio[2], labs[2], audio=True).item()
+    assert abs(loss_a - loss_b) < 1e-5, (loss_a, loss_b)
+    assert (m2.flat.P - P_a).abs().max().item() < 2e-5
+    assert abs(tr2.lr_dev.item() - tr.lr_dev.item()) < 1e-12
+
+    # the optimizer state is a valid torch.optim.AdamW state for the reference's parameter order
+    order = ck.reference_parameter_order(m.cfg, 0)
+    opt = torch.optim.AdamW([m2._views[k] for k in order], lr=1e-3)
+    opt.load_state_dict(blob["optimizer_states"][0])
+    assert float(opt.state[m2._views[order[0]]]["step"]) == 2.0
+
+    # bare export (train.py:105-116)
+    tr2.save_checkpoint(str(tmp_path / "last.pt"))
+    sd = torch.load(tmp_path / "last.pt")
+    assert "proj.weight" in sd and not any(k.startswith("model.") for k in sd)
+
+
+def test_train_py_resume_and_export(dev, tmp_path):
+    """train.py end to end on a reference-shaped config: 2 steps, export, then `path=...last.ckpt` resumes."""
+    import train
+    top = """
+num_epochs: 1
+model_type: ${hydra:runtime.choices.model}
+dataset_type: ${hydra:runtime.choices.dataset}
+seed: 365
+path:
+event_length: 128
+mel_length: 256
+num_rows_per_batch: 2
+optim:
+  lr: 2e-4
+  warmup_steps: 10
+  num_epochs: ${num_epochs}
+  num_steps_per_epoch: 100
+  min_lr: 1e-4
+trainer:
+  log_every_n_steps: 1
+dataloader:
+  train:
+    batch_size: 1
+defaults:
+  - model: MT3Net
+  - dataset: Slakh
+"""
+    from test_config_cpu import MODEL
+    (tmp_path / "cfg" / "model").mkdir(parents=True)
+    (tmp_path / "cfg" / "dataset").mkdir()
+    (tmp_path / "cfg" / "config.yaml").write_text(top)
+    (tmp_path / "cfg" / "model" / "MT3Net.yaml").write_text(MODEL % ("mt3_net.MT3Net", ""))
+    (tmp_path / "cfg" / "dataset" / "Slakh.yaml").write_text("train:\n  mel_length: ${mel_length}\n")
+    out = tmp_path / "out"
+    base = ["--config-dir", str(tmp_path / "cfg"), "--config-name", "config"]
+    train.main(base + ["+max_steps=2", f"+output_dir={out}"])
+    ckpt = out / "MT3Net_Slakh" / "version_0" / "checkpoints" / "last.ckpt"
+    assert ckpt.exists() and (ckpt.parent / "last.pt").exists()
+    assert torch.load(ckpt, weights_only=False)["global_step"] == 2
+    out2 = tmp_path / "out2"
+    train.main(base + ["+max_steps=1", f"+output_dir={out2}", f"path={ckpt}"])
+    assert torch.load(out2 / "MT3Net_Slakh" / "version_0" / "checkpoints" / "last.ckpt", weights_only=False)["global_step"] == 3
+    with pytest.raises(ValueError):
+        train.main(base + ["+max_steps=1", f"+output_dir={out2}", "path=weights.bin"])
