@@ -55,6 +55,18 @@ int mrmt3_logmel_fwd(const float* audio, int batch, int n_samples, int hop, cons
                      int n_mels, int max_taps, const int* valid_frames, int normalize, int out_bf16,
                      void* out, void* stream);
 
+/* Same frontend for crops gathered out of ONE long recording (the producer side of
+ * dataset/dataset_2_random.py:329-344,281-306: _random_chunk picks mel_length frames of the song,
+ * _compute_spectrogram runs on those frames alone, _pad_length zero-pads short rows).  Crop b covers
+ * samples [seg_start[b], seg_start[b]+n_samples) of audio[total_samples]; it sees zeros past the end
+ * of the recording and past valid_frames[b]*hop (its own frames only, never its neighbour's), and
+ * output frames >= valid_frames[b] are zero.  seg_start is int64 on the device. */
+int mrmt3_logmel_crops_fwd(const float* audio, long long total_samples, const long long* seg_start,
+                           int batch, int n_samples, int hop, const float* window,
+                           const float* twiddle, const int* fb_start, const int* fb_cnt,
+                           const float* fb_w, int n_mels, int max_taps, const int* valid_frames,
+                           int normalize, int out_bf16, void* out, void* stream);
+
 /* ---- K2/K4/K6/K7/K9: bias-free Linear layers (nn.Linear(bias=False) inside HF T5Block,
  * models/t5.py:51,72,487-490) ----------------------------------------------------------------------
  * NT:  C[M,N] (+)= A[M,K] . B[N,K]^T      forward y = x W^T, and dgrad with a pre-transposed W.

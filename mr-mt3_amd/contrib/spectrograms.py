@@ -134,6 +134,23 @@ def logmel_segments(audio: torch.Tensor, cfg: SpectrogramConfig = SpectrogramCon
                       out_bf16=out_bf16)
 
 
+def logmel_crops(audio: torch.Tensor, start_frames: torch.Tensor, n_frames: int,
+                 cfg: SpectrogramConfig = SpectrogramConfig(), normalize=True, valid_frames=None,
+                 out_bf16=False) -> torch.Tensor:
+    """Crops of ONE recording resident on the GPU -> [B, n_frames, n_mels], without materialising the
+    crops: `start_frames` [B] (int64, in hops) are the `_random_chunk` offsets
+    (dataset/dataset_2_random.py:329-344); each crop is transformed on its own like
+    `_compute_spectrogram` (`:281-290`) does, and frames >= valid_frames[b] come out zero like the
+    rows `_pad_length` appends (`:295-297`)."""
+    if not audio.is_cuda:
+        raise RuntimeError("logmel_crops needs a device tensor (no CPU fallback)")
+    starts = (start_frames.to(device=audio.device, dtype=torch.int64) * cfg.hop_width).contiguous()
+    vf = None if valid_frames is None else valid_frames.to(device=audio.device, dtype=torch.int32).contiguous()
+    return lib.logmel_crops(audio.contiguous().float().view(-1), starts, n_frames * cfg.hop_width,
+                            kernel_tables(cfg, audio.device), valid_frames=vf, normalize=normalize,
+                            out_bf16=out_bf16)
+
+
 def compute_spectrogram(samples, spectrogram_config, device=None):
     """[N] samples (numpy) -> [ceil(N/hop), n_mels] log-mel (numpy, un-normalised), like the
     reference function; runs on `device` (default cuda:0)."""

@@ -44,6 +44,8 @@ __global__ __launch_bounds__(LM_THREADS) void logmel_kernel(
     const float* __restrict__ fb_w,        // [n_mels][max_taps]
     int n_mels, int max_taps,
     const int* __restrict__ valid_frames,  // [B] or null
+    const long long* __restrict__ seg_start,  // [B] sample offsets into one long recording, or null
+    long long total_samples,
     float lo, float hi, int normalize, void* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) c2 buf0[CFFT_N];
   __shared__ __attribute__((aligned(16))) c2 buf1[CFFT_N];
@@ -64,7 +66,17 @@ __global__ __launch_bounds__(LM_THREADS) void logmel_kernel(
   // twiddles -> LDS (8 KiB, L2-resident)
   for (int i = tid; i < CFFT_N; i += LM_THREADS) tw[i] = ((const c2*)twid)[i];
   // windowed frame -> LDS as 1024 complex (even sample = re, odd = im); zero beyond n_samples
+  // batched rows, or crops gathered straight out of one recording: a crop sees zeros past its own end
+  // (its valid frames / the end of the recording), never its neighbour's samples
   const float* src = audio + (size_t)seg * n_samples;
+  if (seg_start != nullptr) {
+    const long long st = seg_start[seg];
+    src = audio + st;
+    long long lim = total_samples - st;
+    if (lim > n_samples) lim = n_samples;
+    if (valid_frames != nullptr && (long long)valid_frames[seg] * hop < lim) lim = (long long)valid_frames[seg] * hop;
+    n_samples = lim > 0 ? (int)lim : 0;
+  }
   const int base = frame * hop;
 #pragma unroll
   for (int r = 0; r < CFFT_N / LM_THREADS; ++r) {
@@ -132,6 +144,26 @@ __global__ __launch_bounds__(LM_THREADS) void logmel_kernel(
   }
 }
 
+static int logmel_launch(const float* audio, int batch, int n_samples, int hop, const float* window,
+                         const float* twiddle, const int* fb_start, const int* fb_cnt, const float* fb_w, int n_mels,
+                         int max_taps, const int* valid_frames, const long long* seg_start, long long total_samples,
+                         int normalize, int out_bf16, void* out, void* stream) {
+  const int n_frames = ceil_div(n_samples, hop);  // pad_end: ceil(n/hop) full windows
+  dim3 grid((unsigned)(batch * n_frames)), block(LM_THREADS);
+  const float lo = -12.f, hi = 5.f;  // MIN_LOG_MEL / MAX_LOG_MEL
+  hipStream_t s = (hipStream_t)stream;
+  if (out_bf16)
+    hipLaunchKernelGGL(logmel_kernel<true>, grid, block, 0, s, audio, n_samples, n_frames, hop, window, twiddle,
+                       fb_start, fb_cnt, fb_w, n_mels, max_taps, valid_frames, seg_start, total_samples, lo, hi, normalize,
+                       out);
+  else
+    hipLaunchKernelGGL(logmel_kernel<false>, grid, block, 0, s, audio, n_samples, n_frames, hop, window, twiddle,
+                       fb_start, fb_cnt, fb_w, n_mels, max_taps, valid_frames, seg_start, total_samples, lo, hi, normalize,
+                       out);
+  MR_CHECK_LAUNCH("logmel_fwd");
+  return MRMT3_OK;
+}
+
 extern "C" int mrmt3_logmel_fwd(const float* audio, int batch, int n_samples, int hop,
                                 const float* window, const float* twiddle, const int* fb_start,
                                 const int* fb_cnt, const float* fb_w, int n_mels, int max_taps,
@@ -139,16 +171,19 @@ extern "C" int mrmt3_logmel_fwd(const float* audio, int batch, int n_samples, in
                                 void* stream) {
   MR_CHECK_ARG(audio && window && twiddle && fb_start && fb_cnt && fb_w && out, "logmel_fwd: null pointer");
   MR_CHECK_ARG(batch > 0 && n_samples > 0 && hop > 0 && n_mels > 0 && max_taps > 0, "logmel_fwd: bad sizes");
-  const int n_frames = ceil_div(n_samples, hop);  // pad_end: ceil(n/hop) full windows
-  dim3 grid((unsigned)(batch * n_frames)), block(LM_THREADS);
-  const float lo = -12.f, hi = 5.f;  // MIN_LOG_MEL / MAX_LOG_MEL
-  hipStream_t s = (hipStream_t)stream;
-  if (out_bf16)
-    hipLaunchKernelGGL(logmel_kernel<true>, grid, block, 0, s, audio, n_samples, n_frames, hop, window, twiddle,
-                       fb_start, fb_cnt, fb_w, n_mels, max_taps, valid_frames, lo, hi, normalize, out);
-  else
-    hipLaunchKernelGGL(logmel_kernel<false>, grid, block, 0, s, audio, n_samples, n_frames, hop, window, twiddle,
-                       fb_start, fb_cnt, fb_w, n_mels, max_taps, valid_frames, lo, hi, normalize, out);
-  MR_CHECK_LAUNCH("logmel_fwd");
-  return MRMT3_OK;
+  return logmel_launch(audio, batch, n_samples, hop, window, twiddle, fb_start, fb_cnt, fb_w, n_mels, max_taps,
+                       valid_frames, nullptr, 0, normalize, out_bf16, out, stream);
+}
+
+extern "C" int mrmt3_logmel_crops_fwd(const float* audio, long long total_samples, const long long* seg_start,
+                                      int batch, int n_samples, int hop, const float* window,
+                                      const float* twiddle, const int* fb_start, const int* fb_cnt,
+                                      const float* fb_w, int n_mels, int max_taps, const int* valid_frames,
+                                      int normalize, int out_bf16, void* out, void* stream) {
+  MR_CHECK_ARG(audio && seg_start && window && twiddle && fb_start && fb_cnt && fb_w && out,
+               "logmel_crops_fwd: null pointer");
+  MR_CHECK_ARG(total_samples > 0 && batch > 0 && n_samples > 0 && hop > 0 && n_mels > 0 && max_taps > 0,
+               "logmel_crops_fwd: bad sizes");
+  return logmel_launch(audio, batch, n_samples, hop, window, twiddle, fb_start, fb_cnt, fb_w, n_mels, max_taps,
+                       valid_frames, seg_start, total_samples, normalize, out_bf16, out, stream);
 }

@@ -26,6 +26,7 @@ _SIGS = {
     "mrmt3_version": (ci, []),
     "mrmt3_last_error": (C.c_char_p, []),
     "mrmt3_logmel_fwd": (ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp]),
+    "mrmt3_logmel_crops_fwd": (ci, [vp, C.c_longlong, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp]),
     "mrmt3_gemm_nt": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "mrmt3_gemm_tn_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
@@ -155,6 +156,25 @@ def logmel(audio, tables, valid_frames=None, normalize=True, out_bf16=False):
                                        _p(tables["fb_start"]), _p(tables["fb_cnt"]), _p(tables["fb_w"]), n_mels,
                                        tables["max_taps"], _p(valid_frames), int(normalize), int(out_bf16), _p(out),
                                        _stream()), "logmel_fwd")
+    return out
+
+
+def logmel_crops(audio, seg_start, n_samples, tables, valid_frames=None, normalize=True, out_bf16=False):
+    """audio [total] f32 (one recording), seg_start [B] int64 sample offsets -> [B, ceil(n/hop), n_mels]."""
+    _dev(audio, seg_start)
+    assert audio.dim() == 1 and audio.dtype == torch.float32 and audio.is_contiguous()
+    assert seg_start.dtype == torch.int64 and seg_start.is_contiguous()
+    assert valid_frames is None or (valid_frames.dtype == torch.int32 and valid_frames.numel() == seg_start.numel())
+    B = seg_start.numel()
+    hop, n_mels = tables["hop"], tables["n_mels"]
+    frames = -(-n_samples // hop)
+    out = torch.empty(B, frames, n_mels, device=audio.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    with _Timed("logmel", B * n_samples * 4 + out.numel() * out.element_size(), "B"):
+        _check(load().mrmt3_logmel_crops_fwd(_p(audio), audio.numel(), _p(seg_start), B, n_samples, hop,
+                                             _p(tables["window"]), _p(tables["twiddle"]), _p(tables["fb_start"]),
+                                             _p(tables["fb_cnt"]), _p(tables["fb_w"]), n_mels, tables["max_taps"],
+                                             _p(valid_frames), int(normalize), int(out_bf16), _p(out), _stream()),
+               "logmel_crops_fwd")
     return out
 
 

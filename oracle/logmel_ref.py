@@ -142,3 +142,61 @@ def postprocess_batch(result: np.ndarray, eos_id=1, num_special=3) -> np.ndarray
     out = result - num_special
     out = np.where(after_eos.astype(bool), -1, out)
     return out[:, 1:]
+
+
+# ---- producer side of the training dataset (dataset/dataset_2_random.py) -----------------------------------
+# The dataset module itself cannot be imported here (librosa / note_seq / seqio absent): these are
+# line-by-line restatements, PARITY UNPINNED by reference outputs, pinned by known-answer tests only.
+def split_frame(row: dict, length=2000) -> list:
+    """`_split_frame` (dataset_2_random.py:308-327): chunks of `length` frames; the last (partial OR
+    exactly full) chunk is dropped (`split + length >= input_length`); a song shorter than one chunk
+    is returned whole."""
+    per_frame = ("inputs", "input_times", "input_event_start_indices", "input_event_end_indices",
+                 "input_state_event_indices")
+    rows = []
+    n = row["inputs"].shape[0]
+    for split in range(0, n, length):
+        if split + length >= n:
+            continue
+        rows.append({k: (v[split:split + length] if k in per_frame else v) for k, v in row.items()})
+    return rows if rows else [row]
+
+
+def select_rows(rows: list, num_rows_per_batch: int, rng, is_deterministic=False) -> list:
+    """`__getitem__` (`:395-400`): a random run of `num_rows_per_batch` consecutive chunks."""
+    if len(rows) > num_rows_per_batch:
+        start = 0 if is_deterministic else rng.randint(0, len(rows) - num_rows_per_batch)
+        rows = rows[start:start + num_rows_per_batch]
+    return rows
+
+
+def random_chunk(row: dict, mel_length: int, rng, is_deterministic=False) -> dict:
+    """`_random_chunk` (`:329-344`): a random window of mel_length frames inside the chunk
+    (`random.randint` is inclusive on both ends)."""
+    per_frame = ("inputs", "input_times", "input_event_start_indices", "input_event_end_indices",
+                 "input_state_event_indices")
+    n = row["inputs"].shape[0]
+    random_length = n - mel_length
+    if random_length < 1:
+        return row
+    start = 0 if is_deterministic else rng.randint(0, random_length)
+    return {k: (v[start:start + mel_length] if k in per_frame else v) for k, v in row.items()}
+
+
+def compute_spectrogram_row(frames: np.ndarray, fb=None) -> np.ndarray:
+    """`_compute_spectrogram` (`:281-290`): flatten the row's frames, log-mel, clip to [-12, 5], scale."""
+    return normalize_mel(compute_spectrogram(np.asarray(frames, dtype=np.float32).reshape(-1), fb))
+
+
+def pad_length(mel: np.ndarray, targets: np.ndarray, mel_length: int, event_length: int, num_special=3):
+    """`_pad_length` (`:292-306`): mel truncated / zero-padded to mel_length rows; targets truncated to
+    event_length, shifted by the 3 special ids, then EOS(1) and -100 padding IF shorter than
+    event_length (a full-length target gets no EOS)."""
+    inputs = np.asarray(mel[:mel_length], dtype=np.float32)
+    t = np.asarray(targets[:event_length], dtype=np.int64) + num_special
+    if inputs.shape[0] < mel_length:
+        inputs = np.concatenate([inputs, np.zeros((mel_length - inputs.shape[0], inputs.shape[1]), np.float32)], 0)
+    if t.shape[0] < event_length:
+        n_pad = event_length - t.shape[0] - 1
+        t = np.concatenate([t, [1]] + ([np.full(n_pad, -100, np.int64)] if n_pad > 0 else []))
+    return inputs, t

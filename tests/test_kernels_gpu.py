@@ -69,6 +69,56 @@ def test_logmel_edge_cases(dev):
 
 # ---- GEMMs ------------------------------------------------------------------------------------------
 
+def test_logmel_crops_of_one_recording(dev):
+    """GPU-resident batch construction (mrmt3.batching): crops read straight out of the recording ==
+    the oracle's per-crop `_compute_spectrogram` + `_pad_length`, and == materialised crops bit for bit."""
+    import random
+    from contrib import spectrograms as sp
+    from mrmt3.batching import CropPlan, DeviceBatcher
+    from oracle import logmel_ref
+    rs = np.random.RandomState(7)
+    song = rs.uniform(-1, 1, size=9000 * 128 + 37).astype(np.float32)          # not a whole number of frames
+    bt = DeviceBatcher(dev, mel_length=256, num_rows_per_batch=3, split_frame_length=2000, rng=random.Random(5))
+    audio = bt.upload(song)
+    assert audio.numel() == 9001 * 128
+    plan = bt.plan(audio.numel() // 128)
+    assert len(plan.start_frame) == 3 and (plan.valid_frames == 256).all()
+    mel, tg = bt.build(audio, lambda s, n: np.arange(5) + s % 7, plan)
+    assert mel.shape == (3, 256, 512) and tg.shape == (3, 1024) and tg.device.type == "cuda"
+    assert tg[0, :7].tolist() == [3 + plan.start_frame[0] % 7 + i for i in range(5)] + [1, -100]
+    padded = np.concatenate([song, np.zeros(128 - 37, np.float32)])
+    for b, s in enumerate(plan.start_frame):
+        frames = padded[s * 128:(s + 256) * 128].reshape(256, 128)
+        want, _ = logmel_ref.pad_length(logmel_ref.compute_spectrogram_row(frames), np.zeros(1), 256, 1024)
+        np.testing.assert_allclose(mel[b].cpu().numpy(), want, atol=1e-4, rtol=0)
+    crops = torch.stack([audio[s * 128:(s + 256) * 128] for s in plan.start_frame])
+    assert torch.equal(mel, sp.logmel_segments(crops))
+    # a crop never sees its neighbour: zeroing everything outside it changes nothing
+    s0 = int(plan.start_frame[0])
+    alone = torch.zeros_like(audio)
+    alone[s0 * 128:(s0 + 256) * 128] = audio[s0 * 128:(s0 + 256) * 128]
+    one = CropPlan(plan.start_frame[:1], plan.valid_frames[:1], plan.chunk_start[:1])
+    assert torch.equal(bt.mel(alone, one)[0], mel[0])
+    # recording shorter than one window: its 100 frames are transformed on their own, the rest is zero rows
+    short = bt.upload(song[:100 * 128])
+    p = bt.plan(100)
+    m = bt.mel(short, p)
+    want, _ = logmel_ref.pad_length(logmel_ref.compute_spectrogram_row(song[:100 * 128].reshape(100, 128)),
+                                    np.zeros(1), 256, 1024)
+    np.testing.assert_allclose(m[0].cpu().numpy(), want, atol=1e-4, rtol=0)
+    assert (m[0, 100:] == 0).all()
+    # a crop running past the end of the recording reads zeros there, not out of bounds
+    tail = CropPlan(np.asarray([9001 - 40], np.int64), np.asarray([256], np.int32), np.asarray([0], np.int64))
+    mt = bt.mel(audio, tail)
+    ref_tail = np.zeros(256 * 128, np.float32)
+    ref_tail[:40 * 128] = padded[(9001 - 40) * 128:]
+    np.testing.assert_allclose(mt[0].cpu().numpy(), logmel_ref.compute_spectrogram_row(ref_tail.reshape(256, 128)),
+                               atol=1e-4, rtol=0)
+    # bf16 output feeds the trainer directly
+    btb = DeviceBatcher(dev, num_rows_per_batch=3, out_bf16=True)
+    assert btb.mel(audio, plan).dtype == torch.bfloat16
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 1152, 512), (4096, 512, 384), (130, 2048, 512),
                                    (2048, 512, 1024), (64, 1536, 512)])
 def test_gemm_nt_bf16(dev, M, N, K):
