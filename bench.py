@@ -189,20 +189,34 @@ def main():
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
     }
     if not args.no_roofline:
-        # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings
-        fam = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), max(1, min(args.steps, 3)))
+        # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings.
+        # Pass 1 is the timed configuration: weight-gradient GEMMs run on a second stream, so a launch's
+        # event-to-event duration includes the time it shares the CUs with the kernel it overlaps.
+        # Pass 2 serialises everything on one stream: per-kernel durations in isolation.
+        n_rf = max(1, min(args.steps, 3))
+        fam = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), n_rf)
+        eng = trainer.engine
+        was = eng.overlap_wgrad
+        eng.overlap_wgrad = False
+        fam_iso = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), n_rf)
+        eng.overlap_wgrad = was
     if rank == 0 and not args.no_roofline:
-        total = sum(f["ms"] for f in fam.values())
-        dom = max((k for k in fam if fam[k]["unit"] == "FLOP"), key=lambda k: fam[k]["ms"])
-        f = fam[dom]
-        achieved = f["work"] / (f["ms"] * 1e-3) / 1e12
-        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+        dom = "gemm_nt_bf16"        # forward + dgrad Linear layers: the family with the most FLOPs per step
+
+        def rate(v):
+            return v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "FLOP" else 1e9)
+
+        f, fi = fam[dom], fam_iso[dom]
+        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": rate(f), "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": rate(f) / PEAK_BF16_TFLOPS, "traffic": None,
                            "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
-                           "families_ms_per_step": {k: v["ms"] / max(1, min(args.steps, 3)) for k, v in fam.items()},
-                           "families_achieved": {k: (v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "FLOP" else 1e9))
-                                                 for k, v in fam.items()},
-                           "instrumented_ms_total_per_step": total / max(1, min(args.steps, 3))}
+                           "note": "as timed: wgrad GEMMs overlap on a second stream, durations include CU sharing",
+                           "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam.items()},
+                           "families_achieved": {k: rate(v) for k, v in fam.items()},
+                           "isolated": {"achieved": rate(fi), "frac": rate(fi) / PEAK_BF16_TFLOPS,
+                                        "avg_launch_ms": fi["ms"] / fi["n"],
+                                        "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam_iso.items()},
+                                        "families_achieved": {k: rate(v) for k, v in fam_iso.items()}}}
     sync()
     if rank == 0 and not args.no_inference:
         del trainer, model

@@ -50,6 +50,39 @@ __device__ __forceinline__ float gelu_new_d(float x) {
 #define ST_NPRE 3   // number of prefix (memory) positions fed before the start token
 #define ST_FLAGS 4
 
+// ---- several wave-wide sums at once -------------------------------------------------------------------
+// N (power of two, <= 16) values per lane are summed over the 64 lanes with a transposing butterfly:
+// at the xor-32 step each half of the wave keeps half of the values (adds its partner's copy of those
+// and hands over the rest), at xor-16 a quarter, ... so N sums cost N-1 + (6 - log2 N) shuffles instead
+// of 6N, and every addition pairs the same two partial sums as the plain butterfly does (bitwise the
+// same totals).  Afterwards lane L holds the total of value vidx<N>(L) in v[0] (all lanes with the same
+// vidx hold the same number).
+template <int N> __device__ __forceinline__ constexpr int ilog2() { return N <= 1 ? 0 : 1 + ilog2<N / 2>(); }
+template <int N> __device__ __forceinline__ int vidx(int lane) {
+  // value index owned by `lane`: bit 5 of the lane selects the top bit of the index, bit 4 the next, ...
+  int idx = 0;
+#pragma unroll
+  for (int j = 0; j < ilog2<N>(); ++j) idx |= ((lane >> (5 - j)) & 1) << (ilog2<N>() - 1 - j);
+  return idx;
+}
+template <int N> __device__ __forceinline__ void wave_sum_multi(float (&v)[N], int lane) {
+  static_assert(N >= 1 && N <= 16 && (N & (N - 1)) == 0, "N must be a power of two <= 16");
+  int off = 32;
+#pragma unroll
+  for (int n = N; n > 1; n >>= 1, off >>= 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) {
+      const float give = up ? v[i] : v[i + n / 2];
+      const float keep = up ? v[i + n / 2] : v[i];
+      v[i] = keep + __shfl_xor(give, off, 64);
+    }
+  }
+#pragma unroll
+  for (; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
+}
+template <int N> struct Pow2 { static constexpr int v = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : 16; };
+
 // ---- norm + gemv: every WAVE normalises x[b] for itself from registers (8 elements per lane, one
 // wave_sum per sequence) — no LDS, no workgroup barrier — then streams its weight rows with 16-byte
 // loads, all rows' loads issued before the first dot product.
@@ -76,40 +109,95 @@ __global__ __launch_bounds__(256) void dec_norm_gemv(const float* __restrict__ x
   float lw[8];
   load8<float>(lnw + lane * 8, lw);
   float xn[NB][8];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    load8<float>(x + b * DMODEL + lane * 8, xn[b]);
+  if constexpr (NB == 1) {
+    load8<float>(x + lane * 8, xn[0]);
     float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss = fmaf(xn[b][e], xn[b][e], ss);
+    for (int e = 0; e < 8; ++e) ss = fmaf(xn[0][e], xn[0][e], ss);
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)DMODEL + eps);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xn[b][e] = lw[e] * (xn[b][e] * rstd);
-  }
-  const int t = (MODE == 1) ? state[ST_T] : 0;
+    for (int e = 0; e < 8; ++e) xn[0][e] = lw[e] * (xn[0][e] * rstd);
+  } else {
+    constexpr int NP = Pow2<NB>::v;
+    float ss[NP];
 #pragma unroll
-  for (int r = 0; r < GV_ROWS; ++r) {
-    const int n = n0 + r;
-    if (n >= N) break;
+    for (int b = 0; b < NP; ++b) {
+      ss[b] = 0.f;
+      if (b < NB) {
+        load8<float>(x + b * DMODEL + lane * 8, xn[b]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss[b] = fmaf(xn[b][e], xn[b][e], ss[b]);
+      }
+    }
+    wave_sum_multi<NP>(ss, lane);
+    const float mine = rsqrtf(ss[0] / (float)DMODEL + eps);     // rstd of sequence vidx<NP>(lane)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      // sequence b's total sits in the lanes whose top log2(NP) bits spell b: fetch it from the first of them
+      int src = 0;
+#pragma unroll
+      for (int j = 0; j < ilog2<NP>(); ++j) src |= ((b >> (ilog2<NP>() - 1 - j)) & 1) << (5 - j);
+      const float rstd = __shfl(mine, src, 64);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xn[b][e] = lw[e] * (xn[b][e] * rstd);
+    }
+  }
+  const int t = (MODE == 1) ? state[ST_T] : 0;
+  if constexpr (NB == 1) {
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s0 = fmaf(w0[r][e], xn[b][e], s0);
-        if (MODE == 2) s1 = fmaf(w1[r][e], xn[b][e], s1);
+        s0 = fmaf(w0[r][e], xn[0][e], s0);
+        if (MODE == 2) s1 = fmaf(w1[r][e], xn[0][e], s1);
       }
       s0 = wave_sum(s0);
       if (MODE == 2) s1 = wave_sum(s1);
       if (lane == 0) {
-        if (MODE == 0) out[(size_t)b * N + n] = s0;
-        else if (MODE == 2) out[(size_t)b * N + n] = gelu_new_d(s0) * s1;
+        if (MODE == 0) out[n] = s0;
+        else if (MODE == 2) out[n] = gelu_new_d(s0) * s1;
         else {
-          if (n < inner) out[(size_t)b * inner + n] = s0;
-          else if (n < 2 * inner) stf<TW>(kc + b * cache_bstride + (size_t)t * inner + (n - inner), s0);
-          else stf<TW>(vc + b * cache_bstride + (size_t)t * inner + (n - 2 * inner), s0);
+          if (n < inner) out[n] = s0;
+          else if (n < 2 * inner) stf<TW>(kc + (size_t)t * inner + (n - inner), s0);
+          else stf<TW>(vc + (size_t)t * inner + (n - 2 * inner), s0);
         }
+      }
+    }
+  } else {
+    // all GV_ROWS x NB dot products of this wave reduced together; value index = r * NP + b
+    constexpr int NP = Pow2<NB>::v, NV = GV_ROWS * NP;
+    float d0[NV], d1[NV];
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+      for (int b = 0; b < NP; ++b) {
+        float s0 = 0.f, s1 = 0.f;
+        if (b < NB) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s0 = fmaf(w0[r][e], xn[b][e], s0);
+            if (MODE == 2) s1 = fmaf(w1[r][e], xn[b][e], s1);
+          }
+        }
+        d0[r * NP + b] = s0;
+        d1[r * NP + b] = s1;
+      }
+    wave_sum_multi<NV>(d0, lane);
+    if constexpr (MODE == 2) wave_sum_multi<NV>(d1, lane);
+    const int vi = vidx<NV>(lane), r = vi / NP, b = vi % NP, n = n0 + r;
+    constexpr int OWN = 64 / NV;                 // lanes holding the same total: the first of them writes
+    if ((lane & (OWN - 1)) == 0 && b < NB && n < N) {
+      const float s0 = d0[0];
+      if (MODE == 0) out[(size_t)b * N + n] = s0;
+      else if (MODE == 2) out[(size_t)b * N + n] = gelu_new_d(s0) * d1[0];
+      else {
+        if (n < inner) out[(size_t)b * inner + n] = s0;
+        else if (n < 2 * inner) stf<TW>(kc + b * cache_bstride + (size_t)t * inner + (n - inner), s0);
+        else stf<TW>(vc + b * cache_bstride + (size_t)t * inner + (n - 2 * inner), s0);
       }
     }
   }
@@ -135,6 +223,13 @@ __global__ __launch_bounds__(256) void dec_gemv_res(const float* __restrict__ a,
         for (int e = 0; e < 8; ++e) w[r][c][e] = 0.f;
       }
     }
+  // the residual value this lane will update is requested now, not after the reduction
+  constexpr int NP = Pow2<NB>::v, NV = GV_ROWS * NP, OWN = 64 / NV;
+  const int vi = vidx<NV>(lane), wr = vi / NP, wb = vi % NP;
+  const bool writer = (NB == 1) ? (lane < GV_ROWS && n0 + lane < N)
+                                : ((lane & (OWN - 1)) == 0 && wb < NB && n0 + wr < N);
+  float* xdst = (NB == 1) ? x + n0 + lane : x + (size_t)wb * N + n0 + wr;
+  const float xold = writer ? *xdst : 0.f;
   float acc[GV_ROWS][NB];
 #pragma unroll
   for (int r = 0; r < GV_ROWS; ++r)
@@ -154,20 +249,31 @@ __global__ __launch_bounds__(256) void dec_gemv_res(const float* __restrict__ a,
           for (int e = 0; e < 8; ++e) acc[r][b] = fmaf(w[r][c][e], av[e], acc[r][b]);
       }
     }
+  if constexpr (NB == 1) {
+    float sums[GV_ROWS];
 #pragma unroll
-  for (int r = 0; r < GV_ROWS; ++r) {
-    if (n0 + r >= N) break;
+    for (int r = 0; r < GV_ROWS; ++r) sums[r] = wave_sum(acc[r][0]);
+    float mine = sums[0];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const float s = wave_sum(acc[r][b]);
-      if (lane == 0) x[(size_t)b * N + n0 + r] += s;
-    }
+    for (int r = 1; r < GV_ROWS; ++r) mine = (lane == r) ? sums[r] : mine;
+    if (writer) *xdst = xold + mine;
+  } else {
+    float d[NV];
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+      for (int b = 0; b < NP; ++b) d[r * NP + b] = b < NB ? acc[r][b] : 0.f;
+    wave_sum_multi<NV>(d, lane);
+    if (writer) *xdst = xold + d[0];
   }
 }
 
 // one (head, batch) per workgroup: softmax(q.K^T) V over `len` cached rows (len = t+1 or fixed).
-// Scores: one key per thread (8 x 16-byte loads of the key row).  PV: thread = (32 key lanes) x
-// (8 dim-groups of 8): 16-byte V loads, 32 independent partial sums reduced through LDS.
+// The kernel is a chain of L2 round trips, so every phase issues all the loads it can before it waits:
+// scores: one key per thread (8 x 16-byte loads of the key row), the first batch requested before q is
+// staged and each later batch requested before the previous one is consumed.  PV: thread = (32 key
+// lanes) x (8 dim-groups of 8), eight predicated 16-byte V loads in flight per thread, 32 independent
+// partial sums reduced through LDS.
 template <typename TC>
 __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, const TC* __restrict__ kb,
                                                 const TC* __restrict__ vb, int ld, size_t bstride, int fixed_len,
@@ -180,28 +286,48 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
   float* qs = sm + ((len + 3) & ~3);
   float* red = qs + 64;
   float* part = red + 8;
-  if (tid < 64) qs[tid] = q[(size_t)b * inner + h * 64 + tid];
-  __syncthreads();
   const TC* kp = kb + b * bstride + h * 64;
   const TC* vp = vb + b * bstride + h * 64;
-  float mx = -INFINITY;
-  for (int key = tid; key < len; key += 256) {
-    const TC* kr = kp + (size_t)key * ld;
-    float kv[8][8];
+  const int nb = (len + 255) >> 8;            // key batches of 256 (block-uniform)
+  float kva[8][8], kvb[8][8];
+  auto fetch = [&](float (&dst)[8][8], int key) {
+    const TC* kr = kp + (size_t)min(key, len - 1) * ld;
 #pragma unroll
-    for (int d0 = 0; d0 < 8; ++d0) load8<TC>(kr + d0 * 8, kv[d0]);
+    for (int d0 = 0; d0 < 8; ++d0) load8<TC>(kr + d0 * 8, dst[d0]);
+  };
+  fetch(kva, tid);
+  if (tid < 64) qs[tid] = q[(size_t)b * inner + h * 64 + tid];
+  __syncthreads();
+  float mx = -INFINITY;
+  auto score = [&](const float (&src)[8][8], int key) {
     float s = 0.f;
 #pragma unroll
     for (int d0 = 0; d0 < 8; ++d0)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(qs[d0 * 8 + e], kv[d0][e], s);
-    sc[key] = s;
-    mx = fmaxf(mx, s);
+      for (int e = 0; e < 8; ++e) s = fmaf(qs[d0 * 8 + e], src[d0][e], s);
+    if (key < len) {
+      sc[key] = s;
+      mx = fmaxf(mx, s);
+    }
+  };
+  for (int it = 0; it < nb; it += 2) {
+    const int key = it * 256 + tid;
+    if (it + 1 < nb) fetch(kvb, key + 256);
+    score(kva, key);
+    if (it + 1 < nb) {
+      if (it + 2 < nb) fetch(kva, key + 512);
+      score(kvb, key + 256);
+    }
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  // V rows of the first PV batch are requested before the exponentials
+  const int dg = tid & 7, kl = tid >> 3;   // 8 dims per thread, 32 key lanes
+  float vv[8][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) load8<TC>(vp + (size_t)min(kl + 32 * u, len - 1) * ld + dg * 8, vv[u]);
   float se = 0.f;
   for (int key = tid; key < len; key += 256) {
     const float p = expf(sc[key] - mx);
@@ -212,16 +338,21 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
   if (lane == 0) red[4 + wave] = se;
   __syncthreads();
   se = (red[4] + red[5]) + (red[6] + red[7]);
-  const int dg = tid & 7, kl = tid >> 3;   // 8 dims per thread, 32 key lanes
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int key = kl; key < len; key += 32) {
-    float vv[8];
-    load8<TC>(vp + (size_t)key * ld + dg * 8, vv);
-    const float p = sc[key];
+  for (int k0 = kl; k0 < len; k0 += 256) {
+    float pr[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vv[e], acc[e]);
+    for (int u = 0; u < 8; ++u) pr[u] = (k0 + 32 * u < len) ? sc[k0 + 32 * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pr[u], vv[u][e], acc[e]);
+    if (k0 + 256 < len) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) load8<TC>(vp + (size_t)min(k0 + 256 + 32 * u, len - 1) * ld + dg * 8, vv[u]);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) part[kl * 64 + dg * 8 + e] = acc[e];
@@ -235,13 +366,11 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
 }
 
 // argmax + EOS bookkeeping (models/t5.py:286-295) + embedding of the next token; single workgroup
-__global__ __launch_bounds__(256) void dec_argmax(const float* __restrict__ logits, int V, int B, int64_t* __restrict__ tokens,
+__global__ __launch_bounds__(512) void dec_argmax(const float* __restrict__ logits, int V, int B, int64_t* __restrict__ tokens,
                                                   int tok_ld, const float* __restrict__ embed, const float* __restrict__ pos,
                                                   float* __restrict__ x, int* __restrict__ state, int eos, int pad,
                                                   const float* __restrict__ prefix) {
-  __shared__ float bv[4];
-  __shared__ int bi[4];
-  __shared__ int nxt_s;
+  __shared__ int bi[DEC_MAXB];          // per-sequence finished flag after this step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = state[ST_T];            // position just processed
   const int npre = state[ST_NPRE];
@@ -252,20 +381,30 @@ __global__ __launch_bounds__(256) void dec_argmax(const float* __restrict__ logi
       const float* er = (p + 1 < npre) ? prefix + ((size_t)b * npre + p + 1) * DMODEL
                                        : embed + (size_t)tokens[(size_t)b * tok_ld] * DMODEL;
       const float* pr = pos + (size_t)(p + 1) * DMODEL;
-      x[b * DMODEL + tid] = er[tid] + pr[tid];
-      x[b * DMODEL + 256 + tid] = er[256 + tid] + pr[256 + tid];
+      x[b * DMODEL + tid] = er[tid] + pr[tid];          // 512 threads = DMODEL
     }
     if (tid == 0) state[ST_T] = p + 1;
     return;
   }
   const int t = p - npre;               // token step
-  int all_done = 1;
-  for (int b = 0; b < B; ++b) {
+  // one wave per sequence: first-maximum argmax, EOS bookkeeping, next embedding.  Everything that
+  // does not depend on the winner (finished flag, positional row) is requested up front.
+  if (wave < B) {
+    const int b = wave;
+    const int was_done = state[ST_FLAGS + b];
+    const float* pr = pos + (size_t)(p + 1) * DMODEL;
+    float pv[DMODEL / 64];
+#pragma unroll
+    for (int c = 0; c < DMODEL / 64; ++c) pv[c] = pr[c * 64 + lane];
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int c = tid; c < V; c += 256) {
-      const float v = logits[(size_t)b * V + c];
-      if (v > best) { best = v; idx = c; }   // ascending c per thread: first maximum wins
+    for (int c0 = lane; c0 < V; c0 += 512) {
+      float lv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) lv[u] = (c0 + 64 * u < V) ? logits[(size_t)b * V + c0 + 64 * u] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (lv[u] > best) { best = lv[u]; idx = c0 + 64 * u; }   // ascending c per lane: first maximum wins
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -273,27 +412,20 @@ __global__ __launch_bounds__(256) void dec_argmax(const float* __restrict__ logi
       const int oi = __shfl_xor(idx, off, 64);
       if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
     }
-    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 4; ++w)
-        if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-      const int was_done = state[ST_FLAGS + b];
-      int nxt = was_done ? pad : idx;
+    const int nxt = was_done ? pad : idx;
+    const float* er = embed + (size_t)nxt * DMODEL;
+#pragma unroll
+    for (int c = 0; c < DMODEL / 64; ++c) x[b * DMODEL + c * 64 + lane] = er[c * 64 + lane] + pv[c];
+    if (lane == 0) {
       if (!was_done && nxt == eos) state[ST_FLAGS + b] = 1;
       tokens[(size_t)b * tok_ld + t + 1] = nxt;
-      nxt_s = nxt;
+      bi[b] = was_done || nxt == eos;
     }
-    __syncthreads();
-    const int nxt = nxt_s;
-    all_done &= state[ST_FLAGS + b];
-    const float* er = embed + (size_t)nxt * DMODEL;
-    const float* pr = pos + (size_t)(p + 1) * DMODEL;
-    x[b * DMODEL + tid] = er[tid] + pr[tid];
-    x[b * DMODEL + 256 + tid] = er[256 + tid] + pr[256 + tid];
-    __syncthreads();
   }
+  __syncthreads();
   if (tid == 0) {
+    int all_done = 1;
+    for (int b = 0; b < B; ++b) all_done &= bi[b];
     if (all_done && !state[ST_ALL]) { state[ST_ALL] = 1; state[ST_FIN] = t; }
     state[ST_T] = p + 1;
   }
@@ -375,10 +507,10 @@ extern "C" int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_mod
 
 extern "C" void mrmt3_decoder_destroy(mrmt3_decoder* D) {
   if (!D) return;
-  if (D->exec) hipGraphExecDestroy(D->exec);
-  if (D->graph) hipGraphDestroy(D->graph);
+  if (D->exec) (void)hipGraphExecDestroy(D->exec);
+  if (D->graph) (void)hipGraphDestroy(D->graph);
   void* bufs[] = {D->kc, D->vc, D->x, D->q, D->o, D->g, D->logits, D->state};
-  for (void* b : bufs) if (b) hipFree(b);
+  for (void* b : bufs) if (b) (void)hipFree(b);
   delete D;
 }
 
@@ -454,7 +586,7 @@ static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   hipLaunchKernelGGL((dec_norm_gemv<TW, 0, NB>), dim3(ceil_div(V, rows_per_wg)), dim3(256), 0, s, D->x, D->w.final_ln,
                      (const TW*)D->w.lm_head, V, D->eps, D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
                      D->state);
-  hipLaunchKernelGGL(dec_argmax, dim3(1), dim3(256), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
+  hipLaunchKernelGGL(dec_argmax, dim3(1), dim3(512), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
                      (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad, D->prefix);
   MR_CHECK_LAUNCH("decoder step");
   return MRMT3_OK;
@@ -482,8 +614,8 @@ extern "C" int mrmt3_decoder_run(mrmt3_decoder* D, int n_steps, void* stream) {
   MR_CHECK_ARG(D && D->tokens && n_steps >= 0, "decoder_run: call decoder_begin first");
   hipStream_t s = (hipStream_t)stream;
   if (!D->captured && !D->graph_failed) {
-    if (D->exec) { hipGraphExecDestroy(D->exec); D->exec = nullptr; }
-    if (D->graph) { hipGraphDestroy(D->graph); D->graph = nullptr; }
+    if (D->exec) { (void)hipGraphExecDestroy(D->exec); D->exec = nullptr; }
+    if (D->graph) { (void)hipGraphDestroy(D->graph); D->graph = nullptr; }
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
       int rc = step(D, s);

@@ -63,8 +63,10 @@ __device__ __forceinline__ f32x4 mfma_step(f32x4 a, f32x4 b, f32x4 c) {
 // LDS rows are 64 B; chunk c (16 B) of row r is stored at c ^ (2 * ((r >> 3) & 1)), applied on the
 // glds source address and on the ds_read_b128 fragment reads (conflict-free for the b128 lane groups).
 // pipeline of the 256x256 tile: 128-B K steps x 2 stages measured 2-9 % faster than 64 B x 3 stages
+#ifndef NT_RB_BIG
 #define NT_RB_BIG 128
 #define NT_ST_BIG 2
+#endif
 
 template <typename TIN, typename TOUT, bool ACCUM, int WM, int WN, int RB, int NST>
 __global__ __launch_bounds__(64 * WM * WN, 4) void gemm_nt_kernel(const TIN* __restrict__ A, int lda,
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void gemm_nt_kernel(const TIN* __r
   constexpr int CPR = RB / 16;                // 16-B chunks per row (4 or 8)
   constexpr int A_INSTR = BM / RPI, TOT_INSTR = (BM + BN) / RPI, PER_WAVE = TOT_INSTR / NWAVES;
   static_assert(TOT_INSTR % NWAVES == 0, "staging instructions must divide evenly over the waves");
-  static_assert((RB == 64 && NST == 3) || (RB == 128 && NST == 2), "supported pipelines: 64 B x 3 stages, 128 B x 2 stages");
+  static_assert((RB == 64 && (NST == 3 || NST == 4)) || (RB == 128 && NST == 2), "supported pipelines: 64 B x 3/4 stages, 128 B x 2 stages");
+  static_assert(RB != 64 || PER_WAVE == 2 || PER_WAVE == 3, "vmcnt immediates below assume 2 or 3 staging instructions per wave");
   constexpr int EPC = 16 / sizeof(TIN);       // elements per 16-B chunk
   constexpr int BK = RB / sizeof(TIN);        // elements per K step
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];  // one object
@@ -122,19 +125,25 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void gemm_nt_kernel(const TIN* __r
     // fragment byte offsets inside a stage (row & 8 is the same for rows i*16 + fr, i = 0..3)
     const int fswz = (fg ^ (((fr >> 3) & 1) << 1)) << 4;
     const int offa = (wr * 64 + fr) * RB + fswz, offb = BM * RB + (wc * 64 + fr) * RB + fswz;
-    stage(0, 0);
-    if (nk > 1) stage(1, BK);
+    // NST stages, NST-1 K-steps of global_load_lds in flight
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+      if (st < nk) stage(st, st * BK);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      // tile kt has landed once at most the PER_WAVE loads of tile kt+1 are still outstanding
-      if (kt + 1 < nk) {
+      // tile kt has landed once at most the loads of the (up to NST-2) later tiles are still outstanding
+      const int later = min(NST - 2, nk - 1 - kt);
+      if (later >= 2) {
+        if (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else if (later == 1) {
         if (PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading stage (kt-1)%3
-      if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, (kt + 2) * BK);   // (kt+2)%3 == (cur+2)%3
+      __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done reading stage (kt-1)%NST
+      if (kt + NST - 1 < nk) stage(cur == 0 ? NST - 1 : cur - 1, (kt + NST - 1) * BK);   // (kt+NST-1)%NST == (cur-1)%NST
       const unsigned char* ls = lds + cur * STAGE_BYTES;
       typename Frag<TIN>::type af[4], bfr[4];
 #pragma unroll
