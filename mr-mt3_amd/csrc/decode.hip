@@ -50,222 +50,89 @@ __device__ __forceinline__ float gelu_new_d(float x) {
 #define ST_NPRE 3   // number of prefix (memory) positions fed before the start token
 #define ST_FLAGS 4
 
-// ---- several wave-wide sums at once -------------------------------------------------------------------
-// N (power of two, <= 16) values per lane are summed over the 64 lanes with a transposing butterfly:
-// at the xor-32 step each half of the wave keeps half of the values (adds its partner's copy of those
-// and hands over the rest), at xor-16 a quarter, ... so N sums cost N-1 + (6 - log2 N) shuffles instead
-// of 6N, and every addition pairs the same two partial sums as the plain butterfly does (bitwise the
-// same totals).  Afterwards lane L holds the total of value vidx<N>(L) in v[0] (all lanes with the same
-// vidx hold the same number).
-template <int N> __device__ __forceinline__ constexpr int ilog2() { return N <= 1 ? 0 : 1 + ilog2<N / 2>(); }
-template <int N> __device__ __forceinline__ int vidx(int lane) {
-  // value index owned by `lane`: bit 5 of the lane selects the top bit of the index, bit 4 the next, ...
-  int idx = 0;
-#pragma unroll
-  for (int j = 0; j < ilog2<N>(); ++j) idx |= ((lane >> (5 - j)) & 1) << (ilog2<N>() - 1 - j);
-  return idx;
-}
-template <int N> __device__ __forceinline__ void wave_sum_multi(float (&v)[N], int lane) {
-  static_assert(N >= 1 && N <= 16 && (N & (N - 1)) == 0, "N must be a power of two <= 16");
-  int off = 32;
-#pragma unroll
-  for (int n = N; n > 1; n >>= 1, off >>= 1) {
-    const bool up = (lane & off) != 0;
-#pragma unroll
-    for (int i = 0; i < n / 2; ++i) {
-      const float give = up ? v[i] : v[i + n / 2];
-      const float keep = up ? v[i + n / 2] : v[i];
-      v[i] = keep + __shfl_xor(give, off, 64);
-    }
-  }
-#pragma unroll
-  for (; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off, 64);
-}
-template <int N> struct Pow2 { static constexpr int v = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : 16; };
-
-// ---- norm + gemv: every WAVE normalises x[b] for itself from registers (8 elements per lane, one
-// wave_sum per sequence) — no LDS, no workgroup barrier — then streams its weight rows with 16-byte
-// loads, all rows' loads issued before the first dot product.
+// ---- norm + gemv -------------------------------------------------------------------------------------
+// One wave = one weight row (two for the gated FFN) x ONE sequence; the batch is gridDim.y.  Measured on
+// MI355X: a decode step is a chain of ~66 dependent launches whose length is set by the slowest wave of
+// each, so the lightest possible wave wins — carrying 2 rows or up to 8 sequences per wave (to stream a
+// weight row once) cost 255 / 607 us per step at batch 1 / 8 against 235 / 277 this way; the re-read of
+// a weight row by the other sequences' waves is an L2 hit.
+// Every wave normalises x[b] for itself from registers (8 elements per lane, one wave_sum) — no LDS, no
+// workgroup barrier — and requests its weight row before anything else.
 // MODE 0: out[b][n] (f32, ld = N)      — cross-attention q, lm_head logits
 // MODE 1: fused q|k|v: n < inner -> q scratch; else K / V cache row t of this layer
 // MODE 2: gated GELU: rows n and n+N of W ([2N][512]) -> out[b][n] = gelu_new(h0) * h1
-#define GV_ROWS 2   // weight rows per wave
-template <typename TW, int MODE, int NB>
-__global__ __launch_bounds__(256) void dec_norm_gemv(const float* __restrict__ x, const float* __restrict__ lnw,
-                                                     const TW* __restrict__ W, int N, float eps,
-                                                     float* __restrict__ out, TW* __restrict__ kc, TW* __restrict__ vc,
-                                                     int inner, size_t cache_bstride, const int* __restrict__ state) {
+#ifndef DEC_WPG
+#define DEC_WPG 4   // waves (rows) per workgroup
+#endif
+template <typename TW, int MODE>
+__global__ __launch_bounds__(64 * DEC_WPG) void dec_norm_gemv(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                             const TW* __restrict__ W, int N, float eps,
+                                                             float* __restrict__ out, TW* __restrict__ kc,
+                                                             TW* __restrict__ vc, int inner, size_t cache_bstride,
+                                                             const int* __restrict__ state) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * GV_ROWS;
-  if (n0 >= N) return;
-  // weight rows first (longest latency), then x
-  float w0[GV_ROWS][8], w1[GV_ROWS][8];
-#pragma unroll
-  for (int r = 0; r < GV_ROWS; ++r) {
-    const int n = min(n0 + r, N - 1);
-    load8<TW>(W + (size_t)n * DMODEL + lane * 8, w0[r]);
-    if (MODE == 2) load8<TW>(W + (size_t)(n + N) * DMODEL + lane * 8, w1[r]);
-  }
-  float lw[8];
+  const int n = blockIdx.x * DEC_WPG + wave, b = blockIdx.y;
+  if (n >= N) return;
+  float w0[8], w1[8], lw[8], xn[8];
+  load8<TW>(W + (size_t)n * DMODEL + lane * 8, w0);
+  if (MODE == 2) load8<TW>(W + (size_t)(n + N) * DMODEL + lane * 8, w1);
   load8<float>(lnw + lane * 8, lw);
-  float xn[NB][8];
-  if constexpr (NB == 1) {
-    load8<float>(x + lane * 8, xn[0]);
-    float ss = 0.f;
+  load8<float>(x + (size_t)b * DMODEL + lane * 8, xn);
+  float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss = fmaf(xn[0][e], xn[0][e], ss);
-    ss = wave_sum(ss);
-    const float rstd = rsqrtf(ss / (float)DMODEL + eps);
+  for (int e = 0; e < 8; ++e) ss = fmaf(xn[e], xn[e], ss);
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)DMODEL + eps);
+  float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xn[0][e] = lw[e] * (xn[0][e] * rstd);
-  } else {
-    constexpr int NP = Pow2<NB>::v;
-    float ss[NP];
-#pragma unroll
-    for (int b = 0; b < NP; ++b) {
-      ss[b] = 0.f;
-      if (b < NB) {
-        load8<float>(x + b * DMODEL + lane * 8, xn[b]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss[b] = fmaf(xn[b][e], xn[b][e], ss[b]);
-      }
-    }
-    wave_sum_multi<NP>(ss, lane);
-    const float mine = rsqrtf(ss[0] / (float)DMODEL + eps);     // rstd of sequence vidx<NP>(lane)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      // sequence b's total sits in the lanes whose top log2(NP) bits spell b: fetch it from the first of them
-      int src = 0;
-#pragma unroll
-      for (int j = 0; j < ilog2<NP>(); ++j) src |= ((b >> (ilog2<NP>() - 1 - j)) & 1) << (5 - j);
-      const float rstd = __shfl(mine, src, 64);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xn[b][e] = lw[e] * (xn[b][e] * rstd);
-    }
+  for (int e = 0; e < 8; ++e) {
+    const float v = lw[e] * (xn[e] * rstd);
+    s0 = fmaf(w0[e], v, s0);
+    if (MODE == 2) s1 = fmaf(w1[e], v, s1);
   }
-  const int t = (MODE == 1) ? state[ST_T] : 0;
-  if constexpr (NB == 1) {
-#pragma unroll
-    for (int r = 0; r < GV_ROWS; ++r) {
-      const int n = n0 + r;
-      if (n >= N) break;
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s0 = fmaf(w0[r][e], xn[0][e], s0);
-        if (MODE == 2) s1 = fmaf(w1[r][e], xn[0][e], s1);
-      }
-      s0 = wave_sum(s0);
-      if (MODE == 2) s1 = wave_sum(s1);
-      if (lane == 0) {
-        if (MODE == 0) out[n] = s0;
-        else if (MODE == 2) out[n] = gelu_new_d(s0) * s1;
-        else {
-          if (n < inner) out[n] = s0;
-          else if (n < 2 * inner) stf<TW>(kc + (size_t)t * inner + (n - inner), s0);
-          else stf<TW>(vc + (size_t)t * inner + (n - 2 * inner), s0);
-        }
-      }
-    }
-  } else {
-    // all GV_ROWS x NB dot products of this wave reduced together; value index = r * NP + b
-    constexpr int NP = Pow2<NB>::v, NV = GV_ROWS * NP;
-    float d0[NV], d1[NV];
-#pragma unroll
-    for (int r = 0; r < GV_ROWS; ++r)
-#pragma unroll
-      for (int b = 0; b < NP; ++b) {
-        float s0 = 0.f, s1 = 0.f;
-        if (b < NB) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s0 = fmaf(w0[r][e], xn[b][e], s0);
-            if (MODE == 2) s1 = fmaf(w1[r][e], xn[b][e], s1);
-          }
-        }
-        d0[r * NP + b] = s0;
-        d1[r * NP + b] = s1;
-      }
-    wave_sum_multi<NV>(d0, lane);
-    if constexpr (MODE == 2) wave_sum_multi<NV>(d1, lane);
-    const int vi = vidx<NV>(lane), r = vi / NP, b = vi % NP, n = n0 + r;
-    constexpr int OWN = 64 / NV;                 // lanes holding the same total: the first of them writes
-    if ((lane & (OWN - 1)) == 0 && b < NB && n < N) {
-      const float s0 = d0[0];
-      if (MODE == 0) out[(size_t)b * N + n] = s0;
-      else if (MODE == 2) out[(size_t)b * N + n] = gelu_new_d(s0) * d1[0];
-      else {
-        if (n < inner) out[(size_t)b * inner + n] = s0;
-        else if (n < 2 * inner) stf<TW>(kc + b * cache_bstride + (size_t)t * inner + (n - inner), s0);
-        else stf<TW>(vc + b * cache_bstride + (size_t)t * inner + (n - 2 * inner), s0);
-      }
+  s0 = wave_sum(s0);
+  if (MODE == 2) s1 = wave_sum(s1);
+  if (lane == 0) {
+    if (MODE == 0) out[(size_t)b * N + n] = s0;
+    else if (MODE == 2) out[(size_t)b * N + n] = gelu_new_d(s0) * s1;
+    else {
+      const int t = state[ST_T];
+      if (n < inner) out[(size_t)b * inner + n] = s0;
+      else if (n < 2 * inner) stf<TW>(kc + b * cache_bstride + (size_t)t * inner + (n - inner), s0);
+      else stf<TW>(vc + b * cache_bstride + (size_t)t * inner + (n - 2 * inner), s0);
     }
   }
 }
 
 // x[b][n] += sum_k a[b][k] * W[n][k]   (O projections and FFN wo, residual add fused); K <= 1024.
-// The activation vector is read straight from L2 into registers (8 per lane per 512-chunk).
-template <typename TW, int NB, int KCH>   // KCH = number of 512-element chunks of K (1 or 2)
-__global__ __launch_bounds__(256) void dec_gemv_res(const float* __restrict__ a, const TW* __restrict__ W,
-                                                    float* __restrict__ x, int N, int K) {
+// Weight row, activation vector and the residual value to update are all requested up front.
+template <typename TW, int KCH>   // KCH = number of 512-element chunks of K (1 or 2)
+__global__ __launch_bounds__(64 * DEC_WPG) void dec_gemv_res(const float* __restrict__ a, const TW* __restrict__ W,
+                                                            float* __restrict__ x, int N, int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * GV_ROWS;
-  if (n0 >= N) return;
-  float w[GV_ROWS][KCH][8];
+  const int n = blockIdx.x * DEC_WPG + wave, b = blockIdx.y;
+  if (n >= N) return;
+  float w[KCH][8], av[KCH][8];
 #pragma unroll
-  for (int r = 0; r < GV_ROWS; ++r)
+  for (int c = 0; c < KCH; ++c) {
+    const int k0 = c * 512 + lane * 8;
+    if (k0 < K) {
+      load8<TW>(W + (size_t)n * K + k0, w[c]);
+      load8<float>(a + (size_t)b * K + k0, av[c]);
+    } else {
 #pragma unroll
-    for (int c = 0; c < KCH; ++c) {
-      const int k0 = c * 512 + lane * 8;
-      if (k0 < K) load8<TW>(W + (size_t)min(n0 + r, N - 1) * K + k0, w[r][c]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) w[r][c][e] = 0.f;
-      }
+      for (int e = 0; e < 8; ++e) { w[c][e] = 0.f; av[c][e] = 0.f; }
     }
-  // the residual value this lane will update is requested now, not after the reduction
-  constexpr int NP = Pow2<NB>::v, NV = GV_ROWS * NP, OWN = 64 / NV;
-  const int vi = vidx<NV>(lane), wr = vi / NP, wb = vi % NP;
-  const bool writer = (NB == 1) ? (lane < GV_ROWS && n0 + lane < N)
-                                : ((lane & (OWN - 1)) == 0 && wb < NB && n0 + wr < N);
-  float* xdst = (NB == 1) ? x + n0 + lane : x + (size_t)wb * N + n0 + wr;
-  const float xold = writer ? *xdst : 0.f;
-  float acc[GV_ROWS][NB];
-#pragma unroll
-  for (int r = 0; r < GV_ROWS; ++r)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) {
-      const int k0 = c * 512 + lane * 8;
-      if (k0 < K) {
-        float av[8];
-        load8<float>(a + (size_t)b * K + k0, av);
-#pragma unroll
-        for (int r = 0; r < GV_ROWS; ++r)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[r][b] = fmaf(w[r][c][e], av[e], acc[r][b]);
-      }
-    }
-  if constexpr (NB == 1) {
-    float sums[GV_ROWS];
-#pragma unroll
-    for (int r = 0; r < GV_ROWS; ++r) sums[r] = wave_sum(acc[r][0]);
-    float mine = sums[0];
-#pragma unroll
-    for (int r = 1; r < GV_ROWS; ++r) mine = (lane == r) ? sums[r] : mine;
-    if (writer) *xdst = xold + mine;
-  } else {
-    float d[NV];
-#pragma unroll
-    for (int r = 0; r < GV_ROWS; ++r)
-#pragma unroll
-      for (int b = 0; b < NP; ++b) d[r * NP + b] = b < NB ? acc[r][b] : 0.f;
-    wave_sum_multi<NV>(d, lane);
-    if (writer) *xdst = xold + d[0];
   }
+  float* xdst = x + (size_t)b * N + n;
+  const float xold = (lane == 0) ? *xdst : 0.f;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < KCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(w[c][e], av[c][e], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) *xdst = xold + acc;
 }
 
 // one (head, batch) per workgroup: softmax(q.K^T) V over `len` cached rows (len = t+1 or fixed).
@@ -274,6 +141,8 @@ __global__ __launch_bounds__(256) void dec_gemv_res(const float* __restrict__ a,
 // staged and each later batch requested before the previous one is consumed.  PV: thread = (32 key
 // lanes) x (8 dim-groups of 8), eight predicated 16-byte V loads in flight per thread, 32 independent
 // partial sums reduced through LDS.
+// (Computing the cross-attention query inside this kernel, 16 rows per wave while the key rows are in
+// flight, saved a launch per layer and cost the same time: reverted.)
 template <typename TC>
 __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, const TC* __restrict__ kb,
                                                 const TC* __restrict__ vb, int ld, size_t bstride, int fixed_len,
@@ -323,7 +192,8 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  // V rows of the first PV batch are requested before the exponentials
+  // V rows of the first PV batch are requested before the exponentials (requesting them at kernel entry,
+  // next to the first key batch, measured the same)
   const int dg = tid & 7, kl = tid >> 3;   // 8 dims per thread, 32 key lanes
   float vv[8][8];
 #pragma unroll
@@ -549,7 +419,7 @@ extern "C" int mrmt3_decoder_set_prefix(mrmt3_decoder* D, const float* prefix, i
   return MRMT3_OK;
 }
 
-template <typename TW, int NB>
+template <typename TW>
 static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   const int B = D->B, inner = D->inner, dff = D->dff, V = D->V;
   const size_t cache_b = (size_t)D->maxLen * inner;             // elements per batch row of a layer's cache
@@ -558,56 +428,39 @@ static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   const size_t attn_shm_self = (size_t)((D->maxLen + 3) & ~3) * sizeof(float) + attn_extra;
   const size_t attn_shm_cross = (size_t)((D->encLen + 3) & ~3) * sizeof(float) + attn_extra;
   const TW* ckv = (const TW*)D->cross_kv;
-  const int rows_per_wg = 4 * GV_ROWS;
+  const dim3 blk(64 * DEC_WPG);
+  auto rows = [&](int n) { return dim3((unsigned)ceil_div(n, DEC_WPG), (unsigned)B); };
   for (int l = 0; l < D->L; ++l) {
     TW* kc = (TW*)D->kc + l * cache_l;
     TW* vc = (TW*)D->vc + l * cache_l;
-    hipLaunchKernelGGL((dec_norm_gemv<TW, 1, NB>), dim3(ceil_div(3 * inner, rows_per_wg)), dim3(256), 0, s, D->x,
-                       (const float*)D->ln_self[l], (const TW*)D->w_qkv[l], 3 * inner, D->eps, D->q, kc, vc, inner,
-                       cache_b, D->state);
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 1>), rows(3 * inner), blk, 0, s, D->x, (const float*)D->ln_self[l],
+                       (const TW*)D->w_qkv[l], 3 * inner, D->eps, D->q, kc, vc, inner, cache_b, D->state);
     hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_self, s, D->q, (const TW*)kc, (const TW*)vc,
                        inner, cache_b, 0, D->state, D->o, inner);
-    hipLaunchKernelGGL((dec_gemv_res<TW, NB, 1>), dim3(ceil_div(DMODEL, rows_per_wg)), dim3(256), 0, s, D->o,
-                       (const TW*)D->w_o_self[l], D->x, DMODEL, inner);
-    hipLaunchKernelGGL((dec_norm_gemv<TW, 0, NB>), dim3(ceil_div(inner, rows_per_wg)), dim3(256), 0, s, D->x,
-                       (const float*)D->ln_cross[l], (const TW*)D->w_q_cross[l], inner, D->eps, D->q, (TW*)nullptr,
-                       (TW*)nullptr, inner, (size_t)0, D->state);
+    hipLaunchKernelGGL((dec_gemv_res<TW, 1>), rows(DMODEL), blk, 0, s, D->o, (const TW*)D->w_o_self[l], D->x, DMODEL,
+                       inner);
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 0>), rows(inner), blk, 0, s, D->x, (const float*)D->ln_cross[l],
+                       (const TW*)D->w_q_cross[l], inner, D->eps, D->q, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
+                       D->state);
     const TW* ck = ckv + (size_t)l * B * D->encLen * 2 * inner;
     hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_cross, s, D->q, ck, ck + inner, 2 * inner,
                        (size_t)D->encLen * 2 * inner, D->encLen, D->state, D->o, inner);
-    hipLaunchKernelGGL((dec_gemv_res<TW, NB, 1>), dim3(ceil_div(DMODEL, rows_per_wg)), dim3(256), 0, s, D->o,
-                       (const TW*)D->w_o_cross[l], D->x, DMODEL, inner);
-    hipLaunchKernelGGL((dec_norm_gemv<TW, 2, NB>), dim3(ceil_div(dff, rows_per_wg)), dim3(256), 0, s, D->x,
-                       (const float*)D->ln_ff[l], (const TW*)D->w_wi[l], dff, D->eps, D->g, (TW*)nullptr, (TW*)nullptr,
-                       inner, (size_t)0, D->state);
-    hipLaunchKernelGGL((dec_gemv_res<TW, NB, 2>), dim3(ceil_div(DMODEL, rows_per_wg)), dim3(256), 0, s, D->g,
-                       (const TW*)D->w_wo[l], D->x, DMODEL, dff);
+    hipLaunchKernelGGL((dec_gemv_res<TW, 1>), rows(DMODEL), blk, 0, s, D->o, (const TW*)D->w_o_cross[l], D->x, DMODEL,
+                       inner);
+    hipLaunchKernelGGL((dec_norm_gemv<TW, 2>), rows(dff), blk, 0, s, D->x, (const float*)D->ln_ff[l],
+                       (const TW*)D->w_wi[l], dff, D->eps, D->g, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0, D->state);
+    hipLaunchKernelGGL((dec_gemv_res<TW, 2>), rows(DMODEL), blk, 0, s, D->g, (const TW*)D->w_wo[l], D->x, DMODEL, dff);
   }
-  hipLaunchKernelGGL((dec_norm_gemv<TW, 0, NB>), dim3(ceil_div(V, rows_per_wg)), dim3(256), 0, s, D->x, D->w.final_ln,
-                     (const TW*)D->w.lm_head, V, D->eps, D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
-                     D->state);
+  hipLaunchKernelGGL((dec_norm_gemv<TW, 0>), rows(V), blk, 0, s, D->x, D->w.final_ln, (const TW*)D->w.lm_head, V, D->eps,
+                     D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0, D->state);
   hipLaunchKernelGGL(dec_argmax, dim3(1), dim3(512), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
                      (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad, D->prefix);
   MR_CHECK_LAUNCH("decoder step");
   return MRMT3_OK;
 }
 
-template <typename TW>
-static int step_b(mrmt3_decoder* D, hipStream_t s) {
-  switch (D->B) {   // batch is a compile-time constant of the kernels: activations live in registers
-    case 1: return launch_step<TW, 1>(D, s);
-    case 2: return launch_step<TW, 2>(D, s);
-    case 3: return launch_step<TW, 3>(D, s);
-    case 4: return launch_step<TW, 4>(D, s);
-    case 5: return launch_step<TW, 5>(D, s);
-    case 6: return launch_step<TW, 6>(D, s);
-    case 7: return launch_step<TW, 7>(D, s);
-    default: return launch_step<TW, 8>(D, s);
-  }
-}
-
 static int step(mrmt3_decoder* D, hipStream_t s) {
-  return D->wdt == MRMT3_BF16 ? step_b<bf16_t>(D, s) : step_b<float>(D, s);
+  return D->wdt == MRMT3_BF16 ? launch_step<bf16_t>(D, s) : launch_step<float>(D, s);
 }
 
 extern "C" int mrmt3_decoder_run(mrmt3_decoder* D, int n_steps, void* stream) {
