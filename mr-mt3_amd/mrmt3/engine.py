@@ -59,6 +59,7 @@ class Engine:
         # the optimizer / the gradient exchange)
         self.overlap_wgrad = os.environ.get("MRMT3_WGRAD_STREAM", "1") != "0"
         self._side = None
+        self._held = []
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def pos(self, device):
@@ -78,24 +79,32 @@ class Engine:
 
     def side_stream(self):
         if self._side is None or self._side.device != torch.cuda.current_stream().device:
-            self._side = torch.cuda.Stream(priority=int(os.environ.get("MRMT3_WGRAD_PRIO", "0")))
+            self._side = torch.cuda.Stream()
+            self._events = [torch.cuda.Event() for _ in range(64)]
+            self._ev_i = 0
         return self._side
 
     def wgrad(self, a, b, out):
-        """out += a^T @ b on the side stream (inputs were produced on the current stream)."""
+        """out += a^T @ b on the side stream (inputs were produced on the current stream).  Kept cheap on the
+        host (45 calls per step): events come from a small ring, the kernel is launched on the side stream
+        directly, and the operands are kept alive by reference until the next join instead of
+        `record_stream` bookkeeping."""
         if not self.overlap_wgrad:
             return lib.gemm_tn(a, b, out, accumulate=True)
         side = self.side_stream()
-        side.wait_event(torch.cuda.current_stream().record_event())
-        with torch.cuda.stream(side):
-            lib.gemm_tn(a, b, out, accumulate=True)
-        a.record_stream(side)
-        b.record_stream(side)
+        ev = self._events[self._ev_i]
+        self._ev_i = (self._ev_i + 1) % len(self._events)
+        ev.record()
+        side.wait_event(ev)
+        lib.gemm_tn(a, b, out, accumulate=True, stream=side)
+        self._held.append((a, b))
 
     def join_wgrad(self):
         """Make the current stream wait for every weight gradient issued so far."""
         if self.overlap_wgrad and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+            # operands may be recycled now: whatever the current stream does next runs after the side work
+            self._held.clear()
 
     def prepare(self, training: bool):
         if self.dt == torch.bfloat16:
