@@ -163,3 +163,131 @@ def to_event(predictions_np, frame_times):
             start -= start % (1 / STEPS_PER_SECOND)
             preds.append({"est_tokens": tokens, "start_time": start})
     return predictions_to_notes(preds)
+
+
+# ---- tokenisation (notes -> training targets); dataset/dataset_2_random.py:108-250, --------------------------
+# contrib/note_sequences.py:48-66,173-256, contrib/run_length_encoding.py:81-189.  Same pinning status as
+# above (note_seq absent): restated from the cited lines, checked by known answers and by the round trip
+# through the decoder restated above.
+def encode_index(etype, value, ranges=RANGES_V1):
+    off = 0
+    for name, lo, hi in ranges:
+        if name == etype:
+            assert lo <= value <= hi
+            return off + value - lo
+        off += hi - lo + 1
+    raise ValueError(etype)
+
+
+def trim_overlapping(notes):
+    """notes: list of [start, end, pitch, velocity, program, is_drum] (mutable lists)."""
+    notes = [list(n) for n in notes]
+    channels = set((n[2], n[4], n[5]) for n in notes)
+    for pitch, program, is_drum in channels:
+        grp = sorted([n for n in notes if (n[2], n[4], n[5]) == (pitch, program, is_drum)], key=lambda n: n[0])
+        for i in range(1, len(grp)):
+            if grp[i - 1][1] > grp[i][0]:
+                grp[i - 1][1] = grp[i][0]
+    return [n for n in notes if n[0] < n[1]]
+
+
+def onsets_offsets_programs(notes):
+    notes = sorted(notes, key=lambda n: (n[5], n[4], n[2]))
+    times = [n[1] for n in notes if not n[5]] + [n[0] for n in notes]
+    values = [(n[2], 0, n[4], False) for n in notes if not n[5]] + [(n[2], n[3], n[4], n[5]) for n in notes]
+    return times, values
+
+
+def velocity_to_bin(velocity, num_bins=1):
+    import math
+    return 0 if velocity == 0 else math.ceil(num_bins * velocity / 127)
+
+
+def event_data_to_events(active, value):
+    pitch, velocity, program, is_drum = value
+    vb = velocity_to_bin(velocity)
+    if is_drum:
+        return [("velocity", vb), ("drum", pitch)]
+    active[(pitch, program)] = vb
+    return [("program", program), ("velocity", vb), ("pitch", pitch)]
+
+
+def state_to_events(active):
+    ev = []
+    for pitch, program in sorted(active.keys(), key=lambda k: k[::-1]):
+        if active[(pitch, program)]:
+            ev += [("program", program), ("pitch", pitch)]
+    ev.append(("tie", 0))
+    return ev
+
+
+def encode_and_index(times, values, frame_times, sps=STEPS_PER_SECOND):
+    indices = np.argsort(times, kind="stable")
+    steps = [round(times[i] * sps) for i in indices]
+    vals = [values[i] for i in indices]
+    active = {}
+    events, state_events, start_idx, state_idx = [], [], [], []
+    cur_step = cur_event_idx = cur_state_event_idx = 0
+    shift = encode_index("shift", 1)
+
+    def fill():
+        while len(start_idx) < len(frame_times) and frame_times[len(start_idx)] < cur_step / sps:
+            start_idx.append(cur_event_idx)
+            state_idx.append(cur_state_event_idx)
+
+    for step, value in zip(steps, vals):
+        while step > cur_step:
+            events.append(shift)
+            cur_step += 1
+            fill()
+            cur_event_idx = len(events)
+            cur_state_event_idx = len(state_events)
+        for e in state_to_events(active):
+            state_events.append(encode_index(*e))
+        for e in event_data_to_events(active, value):
+            events.append(encode_index(*e))
+    while cur_step / sps <= frame_times[-1]:
+        events.append(shift)
+        cur_step += 1
+        fill()
+        cur_event_idx = len(events)
+    end_idx = start_idx[1:] + [len(events)]
+    return (np.array(events), np.array(start_idx), np.array(end_idx), np.array(state_events), np.array(state_idx))
+
+
+def extract_targets(feats, start_frame, n_frames, tie_token=1131):
+    ev, s_idx, e_idx, st, st_idx = feats
+    targets = ev[s_idx[start_frame]:e_idx[start_frame + n_frames - 1]]
+    a = st_idx[start_frame]
+    b = a + 1
+    while st[b - 1] != tie_token:
+        b += 1
+    return np.concatenate([st[a:b], targets], axis=0)
+
+
+def rle_shifts(events, max_shift=1000):
+    ranges = [type_range("velocity"), type_range("program")]
+    shift_steps = total = 0
+    out = []
+    cur = [0, 0]
+    for event in events:
+        if decode_index(int(event))[0] == "shift":
+            shift_steps += 1
+            total += 1
+        else:
+            red = False
+            for i, (lo, hi) in enumerate(ranges):
+                if lo <= event <= hi:
+                    if cur[i] == event:
+                        red = True
+                    cur[i] = event
+            if red:
+                continue
+            if shift_steps > 0:
+                shift_steps = total
+                while shift_steps > 0:
+                    o = min(max_shift, shift_steps)
+                    out.append(o)
+                    shift_steps -= o
+            out.append(int(event))
+    return np.array(out, dtype=np.int64)

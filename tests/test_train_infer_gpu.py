@@ -202,3 +202,34 @@ defaults:
     assert torch.load(out2 / "MT3Net_Slakh" / "version_0" / "checkpoints" / "last.ckpt", weights_only=False)["global_step"] == 3
     with pytest.raises(ValueError):
         train.main(base + ["+max_steps=1", f"+output_dir={out2}", "path=weights.bin"])
+
+
+def test_rows_from_a_recording_feed_the_trainer(dev):
+    """Recording + its notes -> Tokenizer (targets) + DeviceBatcher (crops read on the GPU) -> train_step."""
+    import random
+    from contrib.note_sequences import Note, NoteSequence
+    from mrmt3.batching import DeviceBatcher
+    from mrmt3.tokenizer import Tokenizer
+    from mrmt3.trainer import Trainer
+    rs = np.random.RandomState(3)
+    seconds = 40.0
+    song = rs.uniform(-0.5, 0.5, size=int(seconds * 16000)).astype(np.float32)
+    notes = []
+    for _ in range(400):
+        s = float(rs.uniform(0, seconds - 1))
+        notes.append(Note(s, s + float(rs.uniform(0.05, 0.8)), int(rs.randint(30, 90)), 90, int(rs.choice([0, 33])), False))
+    tk = Tokenizer()
+    feats = tk.tokenize(NoteSequence(notes, seconds), len(song))
+    bt = DeviceBatcher(dev, mel_length=256, event_length=256, num_rows_per_batch=4, split_frame_length=1000,
+                       out_bf16=True, rng=random.Random(1))
+    audio = bt.upload(song)
+    mel, targets = bt.build(audio, tk.targets_for_crop(feats))
+    assert mel.shape == (4, 256, 512) and mel.dtype == torch.bfloat16 and targets.shape == (4, 256)
+    t = targets.cpu().numpy()
+    assert ((t == -100) | ((t >= 1) & (t < 1536))).all() and (t != -100).sum() > 40
+    first_pad = [(row == -100).argmax() if (row == -100).any() else 256 for row in t]
+    assert all(row[p - 1] == 1 for row, p in zip(t, first_pad) if p < 256)          # EOS closes every short row
+    m = _model("t5", dev)
+    tr = Trainer(m, lr=1e-3)
+    losses = [tr.train_step(mel, targets).item() for _ in range(10)]
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0], losses
