@@ -604,59 +604,72 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 }
 
 // fast path for V = NV*256 <= 2048 (MT3: 1536): one WAVE per row, the row lives in registers (one
-// HBM read), statistics by wave shuffles, no LDS and no workgroup barrier.
+// HBM read), statistics by wave shuffles.  A wave walks CE_RPW consecutive rows and the workgroup adds its
+// loss contribution with ONE atomic: one atomic per row (65 536 of them on a single address) cost more
+// than the whole rest of the kernel.
+#define CE_RPW 16
 template <typename TD, int NV>
 __global__ __launch_bounds__(256) void ce_wave_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                       const float* __restrict__ denom, float* __restrict__ loss,
                                                       TD* __restrict__ dlogits, int rows, int weighted, int lo, int hi,
                                                       float grad_scale) {
   constexpr int V = NV * 256;
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* lp = logits + (size_t)row * V;
-  const int64_t t = targets[row];
-  float w, n;
-  ce_weights(t, weighted, lo, hi, &w, &n);
-  TD* dp = dlogits ? dlogits + (size_t)row * V : nullptr;
-  if (w == 0.f) {
-    if (dp) {
-      const float z[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < NV; ++i) store4<TD>(dp + (i * 64 + lane) * 4, z);
-    }
-    return;
-  }
-  float v[NV][4];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    load4<float>(lp + (i * 64 + lane) * 4, v[i]);
-    mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
-  }
-  mx = wave_max(mx);
-  float se = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[i][e] = expf(v[i][e] - mx);
-      se += v[i][e];
-    }
-  se = wave_sum(se);
-  const float lse = mx + logf(se);
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * CE_RPW;
   const float inv_den = 1.f / denom[0];
-  if (lane == 0) atomicAdd(loss, w * (lse - lp[t]) * inv_den);
-  if (dp) {
-    const float gs = w * inv_den * grad_scale / se;
+  float acc = 0.f;
+  for (int row = row0; row < min(row0 + CE_RPW, rows); ++row) {
+    const float* lp = logits + (size_t)row * V;
+    const int64_t t = targets[row];
+    float w, n;
+    ce_weights(t, weighted, lo, hi, &w, &n);
+    TD* dp = dlogits ? dlogits + (size_t)row * V : nullptr;
+    if (w == 0.f) {
+      if (dp) {
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NV; ++i) store4<TD>(dp + (i * 64 + lane) * 4, z);
+      }
+      continue;
+    }
+    float v[NV][4];
+    float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      float g[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = v[i][e] * gs - ((c + e == t) ? w * inv_den * grad_scale : 0.f);
-      store4<TD>(dp + c, g);
+      load4<float>(lp + (i * 64 + lane) * 4, v[i]);
+      mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
     }
+    const float zt = lp[t];
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] = expf(v[i][e] - mx);
+        se += v[i][e];
+      }
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    acc += w * (lse - zt) * inv_den;
+    if (dp) {
+      const float gs = w * inv_den * grad_scale / se;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = v[i][e] * gs - ((c + e == t) ? w * inv_den * grad_scale : 0.f);
+        store4<TD>(dp + c, g);
+      }
+    }
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+    if (tot != 0.f) atomicAdd(loss, tot);
   }
 }
 
@@ -666,7 +679,7 @@ extern "C" int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, con
   MR_CHECK_ARG(logits && targets && denom_dev && loss_dev && rows > 0 && V % 4 == 0, "ce_fwd_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (V == 1536 || V == 1024 || V == 2048 || V == 512) {
-    dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+    dim3 grid((unsigned)ceil_div(rows, 4 * CE_RPW)), block(256);
 #define CEW(TD, NV)                                                                                              \
   hipLaunchKernelGGL((ce_wave_kernel<TD, NV>), grid, block, 0, s, logits, targets, denom_dev, loss_dev, (TD*)dlogits, \
                      rows, weighted, inst_lo, inst_hi, grad_scale)
