@@ -432,9 +432,18 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
 static void tn_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per_split) {
   const int t = ceil_div(N1, TILE) * ceil_div(N2, TILE);
   const int steps = ceil_div(M, TN_ROWS);
-  int s = ceil_div(768, t);               // aim for ~3 workgroups per CU (each split costs a slab round trip)
-  s = s < 1 ? 1 : s;
   const int max_s = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps (512 rows) per split
+  // 512 workgroups are resident at once (2 per CU): a split count that fills exactly one such wave beats
+  // every other choice measured (w_wo 650 -> 785 TF, w_wi 661 -> 698, w_o 394 -> 500), and exactly three
+  // waves beat 1.5 (w_lm 554 -> 604); it must stay <= 8 or a multiple of 8 (one XCD per token range, see kernel)
+  for (int k = 1; k <= 3; ++k)
+    for (int c = 512 * k / t; c >= 1 && c * t * 100 >= 512 * k * (k == 1 ? 93 : 99); --c)
+      if ((c <= 8 || c % 8 == 0) && c <= max_s && ceil_div(M, ceil_div(steps, c) * TN_ROWS) == c) {
+        *tiles = t; *splits = c; *rows_per_split = ceil_div(steps, c) * TN_ROWS;
+        return;
+      }
+  int s = ceil_div(768, t);               // otherwise ~3 workgroups per CU (each split costs a slab round trip)
+  s = s < 1 ? 1 : s;
   if (s > max_s) s = max_s;
   if (s > 8) s = (s + 7) & ~7;            // multiple of 8 -> one XCD per token range (see kernel)
   if (s > max_s) s = max_s >= 8 ? (max_s & ~7) : max_s;
