@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
-  const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+  // causal: later query tiles see more keys; dispatch the heaviest first so the launch does not end on them
+  const int q0 = (P.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
-  const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+  // causal: later query tiles see more keys; dispatch the heaviest first so the launch does not end on them
+  const int q0 = (P.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, h = blockIdx.y, b = blockIdx.z;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;

@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "mr-mt3_amd"))
 import torch
 from mrmt3 import lib
+if os.environ.get("MRMT3_TOOL_LIB"):      # tuning tool only: A/B a variant build of the library
+    lib.LIB_PATH = os.environ["MRMT3_TOOL_LIB"]
 
 dev = torch.device("cuda:0")
 lib.load()
