@@ -17,7 +17,8 @@
 #include "common.h"
 
 #define DMODEL 512
-#define DEC_MAXB 8
+#define DEC_MAXB 64
+#define ST_CNT (ST_FLAGS + DEC_MAXB)   // workgroups of the current argmax launch that have finished
 
 template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
@@ -235,32 +236,47 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
   }
 }
 
-// argmax + EOS bookkeeping (models/t5.py:286-295) + embedding of the next token; single workgroup
+// argmax + EOS bookkeeping (models/t5.py:286-295) + embedding of the next token.  One wave per sequence,
+// 8 sequences per workgroup; the workgroup that finishes last (agent-scope counter) folds the finished
+// flags into the "all done" state and advances the step counter — every other workgroup has read it by then.
+__device__ __forceinline__ void dec_step_close(int* state, int B, int p, int t, bool token_step) {
+  __threadfence();
+  const int old = atomicAdd(&state[ST_CNT], 1);
+  if (old != (int)gridDim.x - 1) return;
+  state[ST_CNT] = 0;
+  if (token_step) {
+    int all_done = 1;
+    for (int b = 0; b < B; ++b) all_done &= __hip_atomic_load(&state[ST_FLAGS + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (all_done && !state[ST_ALL]) { state[ST_ALL] = 1; state[ST_FIN] = t; }
+  }
+  state[ST_T] = p + 1;
+}
+
 __global__ __launch_bounds__(512) void dec_argmax(const float* __restrict__ logits, int V, int B, int64_t* __restrict__ tokens,
                                                   int tok_ld, const float* __restrict__ embed, const float* __restrict__ pos,
                                                   float* __restrict__ x, int* __restrict__ state, int eos, int pad,
                                                   const float* __restrict__ prefix) {
-  __shared__ int bi[DEC_MAXB];          // per-sequence finished flag after this step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = state[ST_T];            // position just processed
   const int npre = state[ST_NPRE];
   if (p + 1 <= npre) {
     // still inside the prefix: the next input is the next memory row, or the start token right after
     // the last one (models/t5_segmem.py:203-213); this step's logits are discarded
-    for (int b = 0; b < B; ++b) {
+    for (int b = blockIdx.x * 8; b < min(B, (int)blockIdx.x * 8 + 8); ++b) {
       const float* er = (p + 1 < npre) ? prefix + ((size_t)b * npre + p + 1) * DMODEL
                                        : embed + (size_t)tokens[(size_t)b * tok_ld] * DMODEL;
       const float* pr = pos + (size_t)(p + 1) * DMODEL;
       x[b * DMODEL + tid] = er[tid] + pr[tid];          // 512 threads = DMODEL
     }
-    if (tid == 0) state[ST_T] = p + 1;
+    __syncthreads();
+    if (tid == 0) dec_step_close(state, B, p, 0, false);
     return;
   }
   const int t = p - npre;               // token step
-  // one wave per sequence: first-maximum argmax, EOS bookkeeping, next embedding.  Everything that
-  // does not depend on the winner (finished flag, positional row) is requested up front.
-  if (wave < B) {
-    const int b = wave;
+  // first-maximum argmax, EOS bookkeeping, next embedding.  Everything that does not depend on the winner
+  // (finished flag, positional row) is requested up front.
+  const int b = blockIdx.x * 8 + wave;
+  if (b < B) {
     const int was_done = state[ST_FLAGS + b];
     const float* pr = pos + (size_t)(p + 1) * DMODEL;
     float pv[DMODEL / 64];
@@ -289,16 +305,10 @@ __global__ __launch_bounds__(512) void dec_argmax(const float* __restrict__ logi
     if (lane == 0) {
       if (!was_done && nxt == eos) state[ST_FLAGS + b] = 1;
       tokens[(size_t)b * tok_ld + t + 1] = nxt;
-      bi[b] = was_done || nxt == eos;
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    int all_done = 1;
-    for (int b = 0; b < B; ++b) all_done &= bi[b];
-    if (all_done && !state[ST_ALL]) { state[ST_ALL] = 1; state[ST_FIN] = t; }
-    state[ST_T] = p + 1;
-  }
+  if (tid == 0) dec_step_close(state, B, p, t, true);
 }
 
 // position 0 becomes the first memory row instead of the start token
@@ -315,7 +325,7 @@ __global__ void dec_prefix_kernel(int B, int n_prefix, const float* prefix, cons
 __global__ void dec_begin_kernel(int B, int64_t* tokens, int tok_ld, const float* embed, const float* pos, float* x,
                                  int* state, int start_id) {
   const int tid = threadIdx.x;
-  if (tid < ST_FLAGS + DEC_MAXB) state[tid] = (tid == ST_FIN) ? -1 : 0;
+  if (tid <= ST_CNT) state[tid] = (tid == ST_FIN) ? -1 : 0;
   for (int b = 0; b < B; ++b) {
     if (tid == 0) tokens[(size_t)b * tok_ld] = start_id;
     x[b * DMODEL + tid] = embed[(size_t)start_id * DMODEL + tid] + pos[tid];
@@ -349,7 +359,7 @@ extern "C" int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_mod
   MR_CHECK_ARG(out, "decoder_create: null out");
   *out = nullptr;
   MR_CHECK_ARG(d_model == DMODEL, "decoder_create: kernels are specialised for d_model = 512");
-  MR_CHECK_ARG(n_layers > 0 && n_layers <= 64 && max_batch > 0 && max_batch <= DEC_MAXB, "decoder_create: need 1..64 layers, batch <= 8");
+  MR_CHECK_ARG(n_layers > 0 && n_layers <= 64 && max_batch > 0 && max_batch <= DEC_MAXB, "decoder_create: need 1..64 layers, batch <= 64");
   MR_CHECK_ARG(d_ff % 8 == 0 && d_ff <= 1024 && n_heads * 64 <= 512 && vocab > 0 && max_len > 0 && max_enc_len > 0, "decoder_create: need d_ff <= 1024, heads*64 <= 512");
   MR_CHECK_ARG(w_dtype == MRMT3_F32 || w_dtype == MRMT3_BF16, "decoder_create: bad dtype");
   mrmt3_decoder* D = new mrmt3_decoder();
@@ -365,7 +375,7 @@ extern "C" int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_mod
   if (e == hipSuccess) e = hipMalloc((void**)&D->o, sizeof(float) * max_batch * D->inner);
   if (e == hipSuccess) e = hipMalloc((void**)&D->g, sizeof(float) * max_batch * d_ff);
   if (e == hipSuccess) e = hipMalloc((void**)&D->logits, sizeof(float) * max_batch * vocab);
-  if (e == hipSuccess) e = hipMalloc((void**)&D->state, sizeof(int) * (ST_FLAGS + DEC_MAXB));
+  if (e == hipSuccess) e = hipMalloc((void**)&D->state, sizeof(int) * (ST_CNT + 1));
   if (e != hipSuccess) {
     mrmt3_set_error("decoder_create: hipMalloc failed: %s", hipGetErrorString(e));
     mrmt3_decoder_destroy(D);
@@ -453,7 +463,7 @@ static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   }
   hipLaunchKernelGGL((dec_norm_gemv<TW, 0>), rows(V), blk, 0, s, D->x, D->w.final_ln, (const TW*)D->w.lm_head, V, D->eps,
                      D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0, D->state);
-  hipLaunchKernelGGL(dec_argmax, dim3(1), dim3(512), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
+  hipLaunchKernelGGL(dec_argmax, dim3((unsigned)ceil_div(B, 8)), dim3(512), 0, s, D->logits, V, B, D->tokens, D->maxLen + 1,
                      (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad, D->prefix);
   MR_CHECK_LAUNCH("decoder step");
   return MRMT3_OK;

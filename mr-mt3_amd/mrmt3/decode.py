@@ -18,6 +18,9 @@ import torch
 from . import lib
 
 
+MAX_DECODE_BATCH = 64      # DEC_MAXB of csrc/decode.hip: sequences decoded together (one wave per row x sequence)
+
+
 class _Weights(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("pos", C.c_void_p), ("lm_head", C.c_void_p), ("final_ln", C.c_void_p)] + \
                [(n, C.POINTER(C.c_void_p)) for n in ("ln_self", "w_qkv", "w_o_self", "ln_cross", "w_q_cross",
@@ -155,8 +158,8 @@ def generate(model, inputs, max_length=1024, poll_every=64):
     enc = eng.encode(inputs.float() if inputs.dtype not in (torch.float32, torch.bfloat16) else inputs)
     if model.VARIANT in ("t5", "segmem_v1"):      # T5SegMem.generate ignores the memory (t5_segmem.py:254-311)
         out = []
-        for b0 in range(0, B, 8):   # the step kernels batch up to 8 rows
-            nb = min(8, B - b0)
+        for b0 in range(0, B, MAX_DECODE_BATCH):
+            nb = min(MAX_DECODE_BATCH, B - b0)
             dec = _decoder_for(model, nb, max_length, Le)
             ckv = dec.cross_kv(enc.view(B, Le, d)[b0:b0 + nb].reshape(nb * Le, d), nb, Le)
             toks, done, fin = dec.run(ckv, nb, Le, max_length, poll_every)

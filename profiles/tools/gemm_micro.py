@@ -21,6 +21,8 @@ NT = [("qkv", Md, 1152, 512, "bf16"), ("o", Md, 512, 384, "f32"), ("cq", Md, 384
       ("d_wo", Md, 1024, 512, "bf16"), ("d_o", Md, 384, 512, "bf16")]
 TN = [("w_qkv", Md, 1152, 512), ("w_o", Md, 512, 384), ("w_wi", Md, 2048, 512), ("w_wo", Md, 512, 1024),
       ("w_lm", Md, 1536, 512), ("w_ckv", Me, 768, 512)]
+if os.environ.get("MRMT3_TN_SWAPPED"):    # orientation study: the same products with the operands exchanged
+    TN = [(n + "^T", M, b, a) for n, M, a, b in TN]
 
 
 def timeit(fn):

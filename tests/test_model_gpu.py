@@ -261,3 +261,29 @@ def test_lightning_style_task_step(dev):
         losses.append(loss.item())
     assert "train_loss" in task.logged and all(np.isfinite(losses))
     assert losses[-1] < losses[0] - 0.05, losses     # lr 0 at step 0 (warm-up), then it learns
+
+
+def test_greedy_large_batch_equals_small_groups(dev):
+    """40 segments decoded as one group (5 argmax workgroups, batch on gridDim.y) == the same segments decoded
+    8 at a time, early EOS included (the last-finishing workgroup folds the finished flags)."""
+    import mrmt3.decode as dec_mod
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel
+    w = golden_weights(T5_SMALL)
+    w["lm_head.weight"] = w["lm_head.weight"].copy()
+    w["lm_head.weight"][1] *= 3.2
+    m = _build("t5", torch.float32, dev)
+    with torch.no_grad():
+        m.flat.load_numpy(w)
+    mel = torch.from_numpy(synth_mel(40, seed=21)).to(dev)
+    big = m.generate(mel, max_length=96)
+    assert m._decoder.graph_captured
+    old = dec_mod.MAX_DECODE_BATCH
+    try:
+        dec_mod.MAX_DECODE_BATCH = 8
+        m._decoder = None
+        small = m.generate(mel, max_length=96)
+    finally:
+        dec_mod.MAX_DECODE_BATCH = old
+        m._decoder = None
+    assert (big == 1).any(), "EOS never fired; raise the boost"
+    assert torch.equal(big, small)
