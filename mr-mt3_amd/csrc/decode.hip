@@ -18,6 +18,9 @@
 
 #define DMODEL 512
 #define DEC_MAXB 64
+#ifndef DEC_MFMA_ABOVE
+#define DEC_MFMA_ABOVE 8   // batches larger than this use the 16-sequence MFMA projections (bf16 weights)
+#endif
 #define ST_CNT (ST_FLAGS + DEC_MAXB)   // workgroups of the current argmax launch that have finished
 
 template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
@@ -32,6 +35,11 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
   v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xFFFF0000u);
   v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xFFFF0000u);
 }
+// activations entering a projection are rounded to the weights' dtype, as in the engine's bf16 GEMMs
+// (identity for the fp32 parity path)
+template <typename TW> __device__ __forceinline__ float act_round(float v);
+template <> __device__ __forceinline__ float act_round<float>(float v) { return v; }
+template <> __device__ __forceinline__ float act_round<bf16_t>(float v) { return bf2f(f2bf(v)); }
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(64 * DEC_WPG) void dec_norm_gemv(const float* __res
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float v = lw[e] * (xn[e] * rstd);
+    const float v = act_round<TW>(lw[e] * (xn[e] * rstd));
     s0 = fmaf(w0[e], v, s0);
     if (MODE == 2) s1 = fmaf(w1[e], v, s1);
   }
@@ -131,9 +139,126 @@ __global__ __launch_bounds__(64 * DEC_WPG) void dec_gemv_res(const float* __rest
 #pragma unroll
   for (int c = 0; c < KCH; ++c)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc = fmaf(w[c][e], av[c][e], acc);
+    for (int e = 0; e < 8; ++e) acc = fmaf(w[c][e], act_round<TW>(av[c][e]), acc);
   acc = wave_sum(acc);
   if (lane == 0) *xdst = xold + acc;
+}
+
+// ---- the same two projections for groups of 16 sequences on the matrix cores (bf16 weights, batch > 8) ----
+// With one sequence per wave every sequence re-reads every weight row from L2 (45.6 MB x B per step: at 64
+// sequences that, not the launch chain, set the step time).  Here a wave multiplies 16 weight rows by 16
+// sequences: D[16 rows][16 seq] = W[16][K] . A^T[K][16] as K/32 v_mfma_f32_16x16x32_bf16, operands loaded
+// straight from global memory in fragment layout (lane = (row or sequence) & 15, k-group = lane >> 4 holds
+// 8 consecutive k).  Same operand precision and the same products as the single-sequence kernels above; only
+// the order of the f32 additions differs.
+__device__ __forceinline__ bf16x8 pack8(const float v[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (short)f2bf(v[e]);
+  return r;
+}
+
+// A workgroup = 16 weight rows x 16 sequences; its 4 waves split K (a projection has only 384-2048 rows, so
+// 16 rows per WAVE would leave most CUs idle and make each busy one pull hundreds of KB), partial tiles are
+// summed through LDS in wave order.
+template <int MODE>
+__global__ __launch_bounds__(256) void dec_norm_gemm16(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                       const bf16_t* __restrict__ W, int N, float eps,
+                                                       float* __restrict__ out, bf16_t* __restrict__ kc,
+                                                       bf16_t* __restrict__ vc, int inner, size_t cache_bstride,
+                                                       const int* __restrict__ state, int B) {
+  constexpr int KB = DMODEL / 32 / 4;          // k-blocks of 32 per wave
+  __shared__ float ssq[4][16];
+  __shared__ float part[2][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int seq = blockIdx.y * 16 + r;
+  const int k0 = wave * (DMODEL / 4) + g * 8;   // this lane's first k
+  const bf16_t* wrow = W + (size_t)min(n0 + r, N - 1) * DMODEL + k0;
+  bf16x8 a0[KB], a1[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    a0[kb] = *(const bf16x8*)(wrow + kb * 32);
+    if (MODE == 2) a1[kb] = *(const bf16x8*)(wrow + (size_t)N * DMODEL + kb * 32);
+  }
+  const float* xs = x + (size_t)min(seq, B - 1) * DMODEL + k0;
+  float xv[KB][8], lw[KB][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    load8<float>(xs + kb * 32, xv[kb]);
+    load8<float>(lnw + k0 + kb * 32, lw[kb]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf(xv[kb][e], xv[kb][e], ss);
+  }
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  if (g == 0) ssq[wave][r] = ss;
+  __syncthreads();
+  const float rstd = rsqrtf(((ssq[0][r] + ssq[1][r]) + (ssq[2][r] + ssq[3][r])) / (float)DMODEL + eps);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = lw[kb][e] * (xv[kb][e] * rstd);
+    const bf16x8 bfr = pack8(v);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[kb], bfr, acc0, 0, 0, 0);
+    if (MODE == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[kb], bfr, acc1, 0, 0, 0);
+  }
+  // D: column = lane & 15 = sequence, rows 4 g + (0..3); element id = (4 g + rr) * 16 + r
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    part[0][wave][(g * 4 + rr) * 16 + r] = acc0[rr];
+    if (MODE == 2) part[1][wave][(g * 4 + rr) * 16 + r] = acc1[rr];
+  }
+  __syncthreads();
+  const int id = threadIdx.x;                   // one output element per thread: row id / 16, sequence id % 16
+  const int n = n0 + (id >> 4), sq = blockIdx.y * 16 + (id & 15);
+  if (n >= N || sq >= B) return;
+  const float s0 = (part[0][0][id] + part[0][1][id]) + (part[0][2][id] + part[0][3][id]);
+  if (MODE == 0) out[(size_t)sq * N + n] = s0;
+  else if (MODE == 2)
+    out[(size_t)sq * N + n] = gelu_new_d(s0) * ((part[1][0][id] + part[1][1][id]) + (part[1][2][id] + part[1][3][id]));
+  else {
+    const int t = state[ST_T];
+    if (n < inner) out[(size_t)sq * inner + n] = s0;
+    else if (n < 2 * inner) kc[sq * cache_bstride + (size_t)t * inner + (n - inner)] = f2bf(s0);
+    else vc[sq * cache_bstride + (size_t)t * inner + (n - 2 * inner)] = f2bf(s0);
+  }
+}
+
+template <int KB>   // K / 32 / 4 : k-blocks per wave
+__global__ __launch_bounds__(256) void dec_gemm16_res(const float* __restrict__ a, const bf16_t* __restrict__ W,
+                                                      float* __restrict__ x, int N, int B) {
+  constexpr int K = KB * 32 * 4;
+  __shared__ float part[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int seq = blockIdx.y * 16 + r;
+  const int k0 = wave * (K / 4) + g * 8;
+  const bf16_t* wrow = W + (size_t)min(n0 + r, N - 1) * K + k0;
+  const float* as = a + (size_t)min(seq, B - 1) * K + k0;
+  const int id = threadIdx.x;
+  const int n = n0 + (id >> 4), sq = blockIdx.y * 16 + (id & 15);
+  const bool live = n < N && sq < B;
+  const float xold = live ? x[(size_t)sq * N + n] : 0.f;
+  bf16x8 wf[KB];
+  float av[KB][8];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    wf[kb] = *(const bf16x8*)(wrow + kb * 32);
+    load8<float>(as + kb * 32, av[kb]);
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kb], pack8(av[kb]), acc, 0, 0, 0);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) part[wave][(g * 4 + rr) * 16 + r] = acc[rr];
+  __syncthreads();
+  if (live) x[(size_t)sq * N + n] = xold + ((part[0][id] + part[1][id]) + (part[2][id] + part[3][id]));
 }
 
 // one (head, batch) per workgroup: softmax(q.K^T) V over `len` cached rows (len = t+1 or fixed).
@@ -430,6 +555,48 @@ extern "C" int mrmt3_decoder_set_prefix(mrmt3_decoder* D, const float* prefix, i
 }
 
 template <typename TW>
+static int launch_step(mrmt3_decoder* D, hipStream_t s);
+
+// batch > 8, bf16 weights: projections on the matrix cores, 16 sequences per wave
+static int launch_step_mfma(mrmt3_decoder* D, hipStream_t s) {
+  typedef bf16_t TW;
+  const int B = D->B, inner = D->inner, dff = D->dff, V = D->V;
+  const size_t cache_b = (size_t)D->maxLen * inner;
+  const size_t cache_l = (size_t)D->maxB * cache_b;
+  const size_t attn_extra = (size_t)(64 + 8 + 32 * 64) * sizeof(float);
+  const size_t attn_shm_self = (size_t)((D->maxLen + 3) & ~3) * sizeof(float) + attn_extra;
+  const size_t attn_shm_cross = (size_t)((D->encLen + 3) & ~3) * sizeof(float) + attn_extra;
+  const TW* ckv = (const TW*)D->cross_kv;
+  const dim3 blk(256);
+  auto rows = [&](int n) { return dim3((unsigned)ceil_div(n, 16), (unsigned)ceil_div(B, 16)); };
+  for (int l = 0; l < D->L; ++l) {
+    TW* kc = (TW*)D->kc + l * cache_l;
+    TW* vc = (TW*)D->vc + l * cache_l;
+    hipLaunchKernelGGL((dec_norm_gemm16<1>), rows(3 * inner), blk, 0, s, D->x, (const float*)D->ln_self[l],
+                       (const TW*)D->w_qkv[l], 3 * inner, D->eps, D->q, kc, vc, inner, cache_b, D->state, B);
+    hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_self, s, D->q, (const TW*)kc, (const TW*)vc,
+                       inner, cache_b, 0, D->state, D->o, inner);
+    hipLaunchKernelGGL((dec_gemm16_res<3>), rows(DMODEL), blk, 0, s, D->o, (const TW*)D->w_o_self[l], D->x, DMODEL, B);
+    hipLaunchKernelGGL((dec_norm_gemm16<0>), rows(inner), blk, 0, s, D->x, (const float*)D->ln_cross[l],
+                       (const TW*)D->w_q_cross[l], inner, D->eps, D->q, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0,
+                       D->state, B);
+    const TW* ck = ckv + (size_t)l * B * D->encLen * 2 * inner;
+    hipLaunchKernelGGL((dec_attn<TW>), dim3(D->H, B), dim3(256), attn_shm_cross, s, D->q, ck, ck + inner, 2 * inner,
+                       (size_t)D->encLen * 2 * inner, D->encLen, D->state, D->o, inner);
+    hipLaunchKernelGGL((dec_gemm16_res<3>), rows(DMODEL), blk, 0, s, D->o, (const TW*)D->w_o_cross[l], D->x, DMODEL, B);
+    hipLaunchKernelGGL((dec_norm_gemm16<2>), rows(dff), blk, 0, s, D->x, (const float*)D->ln_ff[l],
+                       (const TW*)D->w_wi[l], dff, D->eps, D->g, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0, D->state, B);
+    hipLaunchKernelGGL((dec_gemm16_res<8>), rows(DMODEL), blk, 0, s, D->g, (const TW*)D->w_wo[l], D->x, DMODEL, B);
+  }
+  hipLaunchKernelGGL((dec_norm_gemm16<0>), rows(V), blk, 0, s, D->x, D->w.final_ln, (const TW*)D->w.lm_head, V, D->eps,
+                     D->logits, (TW*)nullptr, (TW*)nullptr, inner, (size_t)0, D->state, B);
+  hipLaunchKernelGGL(dec_argmax, dim3((unsigned)ceil_div(B, 8)), dim3(512), 0, s, D->logits, V, B, D->tokens,
+                     D->maxLen + 1, (const float*)D->w.embed, D->w.pos, D->x, D->state, D->eos, D->pad, D->prefix);
+  MR_CHECK_LAUNCH("decoder step (mfma)");
+  return MRMT3_OK;
+}
+
+template <typename TW>
 static int launch_step(mrmt3_decoder* D, hipStream_t s) {
   const int B = D->B, inner = D->inner, dff = D->dff, V = D->V;
   const size_t cache_b = (size_t)D->maxLen * inner;             // elements per batch row of a layer's cache
@@ -470,6 +637,8 @@ static int launch_step(mrmt3_decoder* D, hipStream_t s) {
 }
 
 static int step(mrmt3_decoder* D, hipStream_t s) {
+  if (D->wdt == MRMT3_BF16 && D->B > DEC_MFMA_ABOVE && D->inner == 384 && D->dff == 1024 && D->d == DMODEL)
+    return launch_step_mfma(D, s);
   return D->wdt == MRMT3_BF16 ? launch_step<bf16_t>(D, s) : launch_step<float>(D, s);
 }
 
