@@ -312,3 +312,37 @@ def test_bf16_large_batch_mfma_projections_agree_with_single_sequence_kernels(de
     eq = (big[:, :n] == small[:, :n]).long().cumprod(dim=1).sum(dim=1)
     print("identical prefix lengths:", sorted(eq.tolist()))
     assert (eq == n).float().mean().item() >= 0.6 and eq.min().item() >= 9, sorted(eq.tolist())
+
+
+def test_long_context_finetune_shapes(dev):
+    """BASELINE configs[4] (config_slakh_segmem_finetune.yaml): segmem_v2_with_prev with mel_length 2048, i.e.
+    2048 encoder frames + 64 memory slots as cross-attention keys.  fp32 logits vs the oracle within 2e-4, bf16
+    loss within 1e-3, bf16 gradients cosine > 0.995 for a sample of tensors."""
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel, synth_labels
+    from oracle import t5_ref
+    torch.set_num_threads(8)
+    B, Le, Ld = 1, 2048, 128
+    mel = torch.from_numpy(synth_mel(B * 8, seed=31).reshape(B, Le, 512))
+    lab = torch.from_numpy(synth_labels(B, Ld, full=False, seed=32, mean_len=90))
+    prev = torch.from_numpy(synth_labels(B, Ld, full=False, seed=33, mean_len=90))
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in golden_weights(T5_SMALL, 1).items()}
+    logits = t5_ref.forward_logits(sd, T5_SMALL, mel, lab, variant="segmem_v2_with_prev", targets_prev=prev.clone())
+    ref_loss = t5_ref.ce_loss(logits, lab)
+    ref_loss.backward()
+    m32 = _build("segmem_v2_with_prev", torch.float32, dev)
+    with torch.no_grad():
+        got = m32(inputs=mel.to(dev), labels=lab.to(dev), targets_prev=prev.clone().to(dev))
+    assert got.shape == (B, Ld, 1536)
+    np.testing.assert_allclose(got.cpu().numpy(), logits.detach().numpy(), atol=2e-4, rtol=0)
+    m = _build("segmem_v2_with_prev", torch.bfloat16, dev)        # eval mode: dropout off, autograd bridge on
+    out = m(inputs=mel.to(dev), labels=lab.to(dev), targets_prev=prev.clone().to(dev))
+    loss = torch.nn.functional.cross_entropy(out.view(-1, 1536), lab.to(dev).view(-1), ignore_index=-100)
+    print("long context: bf16 loss %.5f oracle %.5f" % (loss.item(), ref_loss.item()))
+    assert abs(loss.item() - ref_loss.item()) < 1e-3
+    loss.backward()
+    for key in ("encoder.block.0.layer.0.SelfAttention.q.weight", "encoder.block.7.layer.1.DenseReluDense.wo.weight",
+                "decoder.block.0.layer.1.EncDecAttention.k.weight", "segmem_encoder.block.0.layer.0.SelfAttention.v.weight",
+                "proj.weight", "lm_head.weight"):
+        g, r = m.flat.grad(key).float().cpu().reshape(-1), sd[key].grad.reshape(-1)
+        cos = torch.dot(g, r) / (g.norm() * r.norm())
+        assert cos > 0.995, (key, cos.item())
