@@ -129,6 +129,24 @@ def inference_rtf(dev, tokens, batch):
         assert ids.shape == (nb, tokens + 1)
         out[name] = dict(segments=nb, tokens=tokens, seconds=dt, rtf=dt / (nb * SEG_SECONDS),
                          ms_per_token_step=1e3 * dt / tokens, graph=bool(m._decoder.graph_captured))
+    # MR-MT3 proper (segment memory from the previous segment's tokens): a recording is a sequential chain,
+    # several recordings decode in lockstep, one batch row each
+    del m
+    mm = build_model("segmem_v2_with_prev", dev).eval()
+    with torch.no_grad():
+        mm.flat.master("lm_head.weight")[1].zero_()
+    n_seg = 3
+    for name, n_songs in (("mrmt3_1song", 1), ("mrmt3_8songs", 8)):
+        songs = [sp.logmel_segments(audio[i * n_seg:(i + 1) * n_seg], out_bf16=True) for i in range(n_songs)]
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ids = mm.generate_songs(songs, max_length=tokens)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert len(ids) == n_songs and ids[0].shape == (n_seg, tokens)
+        out[name] = dict(recordings=n_songs, segments_each=n_seg, tokens=tokens, seconds=dt,
+                         rtf=dt / (n_songs * n_seg * SEG_SECONDS))
     return out
 
 

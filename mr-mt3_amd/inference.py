@@ -149,3 +149,31 @@ class InferenceHandler:
             os.makedirs(os.path.dirname(os.path.abspath(outpath)), exist_ok=True)
             midi_io.note_sequence_to_midi_file(ns, outpath)
         return ns
+
+    @torch.no_grad()
+    def inference_many(self, audios, outpaths=None, max_length=1024, return_tokens=False):
+        """Several recordings in one go.  Segment-memory models decode them in lockstep (one batch row per
+        recording, `model.generate_songs`); the plain T5 simply batches all segments.  Returns one note sequence
+        (or, with `return_tokens`, one `(token arrays, frame times)` pair) per recording, like `inference`."""
+        pre = [self._preprocess(a) for a in audios]
+        if hasattr(self.model, "generate_songs"):
+            ids = self.model.generate_songs([x.to(self.device) for x, _ in pre], max_length=max_length)
+        else:
+            flat = self.model.generate(inputs=torch.cat([x for x, _ in pre]).to(self.device), max_length=max_length)
+            ids, at = [], 0
+            for x, _ in pre:
+                ids.append(flat[at:at + x.shape[0]])
+                at += x.shape[0]
+        out = []
+        for k, (seg_ids, (_, ft)) in enumerate(zip(ids, pre)):
+            results, times = [self._postprocess_batch(seg_ids)], [ft]
+            if return_tokens:
+                out.append((results, times))
+                continue
+            ns = self._to_event(results, times)
+            if outpaths is not None and outpaths[k] is not None:
+                import os
+                os.makedirs(os.path.dirname(os.path.abspath(outpaths[k])), exist_ok=True)
+                midi_io.note_sequence_to_midi_file(ns, outpaths[k])
+            out.append(ns)
+        return out

@@ -233,3 +233,56 @@ def generate_2(model, inputs, max_length=1024, poll_every=64):
         outs.append(row)
         seg_ids = row
     return torch.cat(outs, 0)
+
+
+@torch.no_grad()
+def generate_songs(model, songs, max_length=1024, poll_every=64):
+    """Several recordings decoded in lockstep with the segment-memory models (V2 / V2WithPrev).
+
+    The reference transcribes one recording at a time because segment i needs segment i-1's tokens
+    (t5_segmem_v2_with_prev.py:241-294) — but recordings are independent of each other.  Here row s of the
+    decode batch is recording s's CURRENT segment: every recording keeps its own memory chain, and each row
+    produces exactly what `generate` produces for that recording alone (same kernels, one wave per row and
+    sequence).  `songs`: list of [n_seg_s, Le, 512] device tensors.  Returns a list of [n_seg_s, max_length]
+    int64 tensors."""
+    eng, cfg = model.engine, model.cfg
+    if model.VARIANT not in ("segmem_v2", "segmem_v2_with_prev"):
+        raise RuntimeError("generate_songs is for the segment-memory models; plain T5 batches segments directly")
+    if not songs:
+        return []
+    if len(songs) > MAX_DECODE_BATCH:
+        out = []
+        for i in range(0, len(songs), MAX_DECODE_BATCH):
+            out += generate_songs(model, songs[i:i + MAX_DECODE_BATCH], max_length, poll_every)
+        return out
+    dev = songs[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("generate_songs needs device tensors (no CPU fallback)")
+    eng.prepare(False)
+    S = len(songs)
+    Le, d = songs[0].shape[1], songs[0].shape[2]
+    Ls = min(model.segmem_length, max_length)
+    enc = [eng.encode(x).view(x.shape[0], Le, d) for x in songs]           # per recording, all its segments
+    first = torch.zeros(max_length, dtype=torch.int64, device=dev)
+    if model.VARIANT == "segmem_v2_with_prev":
+        first[0], first[1] = 1134, 1
+    else:
+        first[0] = 1
+    prev = [first.clone() for _ in range(S)]
+    outs = [[] for _ in range(S)]
+    for i in range(max(x.shape[0] for x in songs)):
+        live = [s for s in range(S) if i < songs[s].shape[0]]
+        B = len(live)
+        seg_ids = torch.stack([prev[s] for s in live])                      # [B, max_length]
+        mem = eng.segmem(seg_ids, B, max_length)                           # [B, Ls, d]
+        cur = torch.cat([torch.stack([enc[s][i] for s in live]), mem.to(enc[0].dtype)], 1).contiguous()
+        dec = _decoder_for(model, B, max_length, Le + Ls)
+        ckv = dec.cross_kv(cur.view(B * (Le + Ls), d), B, Le + Ls)
+        toks, done, fin = dec.run(ckv, B, Le + Ls, max_length, poll_every)
+        rows = toks[:B, :max_length].clone()                               # finished rows are already pad(0)-filled
+        if done < max_length:                                              # all rows hit EOS early: the rest is stale
+            rows[:, done + 1:] = 0
+        for r, s in enumerate(live):
+            outs[s].append(rows[r])
+            prev[s] = rows[r]
+    return [torch.stack(o) for o in outs]

@@ -346,3 +346,23 @@ def test_long_context_finetune_shapes(dev):
         g, r = m.flat.grad(key).float().cpu().reshape(-1), sd[key].grad.reshape(-1)
         cos = torch.dot(g, r) / (g.norm() * r.norm())
         assert cos > 0.995, (key, cos.item())
+
+
+@pytest.mark.parametrize("variant", ["segmem_v2_with_prev", "segmem_v2"])
+def test_lockstep_decode_of_several_recordings_equals_one_at_a_time(dev, variant):
+    """generate_songs: row s of the decode batch is recording s's current segment; every row must produce exactly
+    what the sequential per-recording `generate` produces (fp32, early EOS and ragged segment counts included)."""
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel
+    w = golden_weights(T5_SMALL, 1)
+    w["lm_head.weight"] = w["lm_head.weight"].copy()
+    w["lm_head.weight"][1] *= 3.0          # EOS fires at different steps in different rows
+    m = _build(variant, torch.float32, dev)
+    with torch.no_grad():
+        m.flat.load_numpy(w)
+    songs = [torch.from_numpy(synth_mel(n, seed=40 + n)).to(dev) for n in (3, 1, 2)]
+    together = m.generate_songs(songs, max_length=80)
+    assert [t.shape for t in together] == [(3, 80), (1, 80), (2, 80)]
+    for s, mel in enumerate(songs):
+        alone = m.generate(mel, max_length=80)
+        assert torch.equal(together[s], alone), s
+    assert any((t == 1).any().item() for t in together), "EOS never fired; raise the boost"
