@@ -13,9 +13,9 @@
 //             The scores are computed TRANSPOSED (S^T = K.Q^T, query on the MFMA lane) so that the
 //             softmax row statistics are per-lane scalars and the exponentiated tile is already the
 //             B operand of O^T = V^T.P^T (accumulator-as-operand, no LDS round trip for P).
-//   backward: (1) delta = rowsum(dO*O); (2) dK/dV: workgroup = 128 keys, key on the lane, loops
-//             over 32-query blocks; (3) dQ: workgroup = 128 queries, query on the lane, loops over
-//             64-key tiles.  P is recomputed from the saved log-sum-exp.  No atomics: every output
+//   backward: (1) dQ: workgroup = 128 queries, query on the lane, loops over 64-key tiles; it also derives
+//             delta = rowsum(dO*O) from operands it holds anyway and stores it; (2) dK/dV: workgroup = 128
+//             keys, key on the lane, loops over 32-query blocks.  P is recomputed from the saved log-sum-exp.  No atomics: every output
 //             element has exactly one writer, results are bitwise reproducible.
 // The f32 kernel is a plain exact-f32 implementation used for the fp32 parity / greedy-decode path.
 #include "common.h"
@@ -269,8 +269,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: delta = rowsum(dO * O) per (b, h, q)
-// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams P) {
   // one wave per (b, q) row; lane l covers 8 consecutive columns (16-byte loads), so a head's 64
   // columns live in 8 consecutive lanes and reduce with three shuffles
@@ -474,7 +472,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
       dof[qt][ks] = *(const bf16x8*)(dob + (size_t)r * P.lddo + ks * 32 + fg * 8);
     }
     lse_q[qt] = P.lse[((size_t)b * P.H + h) * P.Lq + r] * LOG2E;
-    dlt_q[qt] = P.delta[((size_t)b * P.H + h) * P.Lq + r];
+    // delta = rowsum(dO * O): this lane has 16 of the row's 64 dO values already; the same 16 of O come in
+    // two 16-byte loads, the four lane groups of a row are summed with two shuffles.  The value is also
+    // written out for the dK/dV kernel, which runs after this one (no separate delta pass over dO and O).
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 of = *(const bf16x8*)(P.o + ((size_t)b * P.Lq + r) * P.ldo + h * HD + ks * 32 + fg * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(bf2f((bf16_t)dof[qt][ks][e]), bf2f((bf16_t)of[e]), part);
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    dlt_q[qt] = part;
+    if (fg == 0 && qrow[qt] < P.Lq) P.delta[((size_t)b * P.H + h) * P.Lq + r] = part;
   }
   f32x4 dqT[2][4];
 #pragma unroll
@@ -677,11 +688,10 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ceil_div(B * Lq, 4)), dim3(256), 0, s, P);
-  MR_CHECK_LAUNCH("attn_bwd delta");
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(ceil_div(Lk, 128), H, B), dim3(256), 0, s, P);
-  MR_CHECK_LAUNCH("attn_bwd dkdv");
+  // dQ first: it derives delta = rowsum(dO * O) from operands it loads anyway and leaves it for dK/dV
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dq");
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(ceil_div(Lk, 128), H, B), dim3(256), 0, s, P);
+  MR_CHECK_LAUNCH("attn_bwd dkdv");
   return MRMT3_OK;
 }
