@@ -93,13 +93,15 @@ int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const flo
                           int out_drop, void* stream);
 /* backward of the above:
  *   g    = dxn (f32 or bf16, dxn_dtype) [* out-dropout mask]
- *   dx1  = dres (nullable) + rmsnorm_bwd(g; x1, rstd, w)          -> dx1 (f32; may alias dres)
+ *   dx1  = dres (nullable) + rmsnorm_bwd(g; x1, rstd, w)          -> dx1 (may alias dres when the dtypes agree)
+ *          dres / dx1 are f32 or — the residual-gradient stream of the bf16 engine, cols == 512 — bf16
  *   dy   = dropmask_y(dx1) as bf16 (nullable)                      -> dy
  *   dw  += sum_rows g * x1 * rstd      (per-workgroup partials in `workspace`, then a 16-way reduction;
  *                                        workspace >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols)) */
 size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols);
-int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float* dres, const float* x1, const float* rstd,
-                          const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
+int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int dres_dtype, const float* x1,
+                          const float* rstd, const float* w, void* dx1, int dx1_dtype, void* dy_bf16,
+                          float* dw, int rows, int cols,
                           float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
                           int out_drop, void* workspace, size_t workspace_bytes, void* stream);
 

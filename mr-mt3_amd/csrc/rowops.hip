@@ -121,10 +121,10 @@ extern "C" int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype
 // backward: each workgroup owns NB_ROWS consecutive rows (wave w takes rows w, w+4, ...), keeps the
 // per-column dw partial sums in registers and issues one f32 atomic per column at the end.
 #define NB_ROWS 32
-template <int NV, typename TG>
-__global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restrict__ dxn, const float* __restrict__ dres,
+template <int NV, typename TG, typename TRI, typename TRO>
+__global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restrict__ dxn, const TRI* __restrict__ dres,
                                                               const float* __restrict__ x1, const float* __restrict__ rstd_in,
-                                                              const float* __restrict__ w, float* __restrict__ dx1,
+                                                              const float* __restrict__ w, TRO* __restrict__ dx1,
                                                               bf16_t* __restrict__ dy, float* __restrict__ dw_part, int rows,
                                                               int cols, DropCfg ddy, DropCfg dout, int out_drop) {
   __shared__ float red[4 * 256 * NV];  // [wave][col]
@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
         for (int e = 0; e < 4; ++e) d[e] = rstd * (g[i][e] - xh[i][e] * dot);
         if (dres != nullptr) {
           float r[4];
-          load4<float>(dres + base + col, r);
+          load4<TRI>(dres + base + col, r);
 #pragma unroll
           for (int e = 0; e < 4; ++e) d[e] += r[e];
         }
-        store4<float>(dx1 + base + col, d);
+        store4<TRO>(dx1 + base + col, d);
         if (dy != nullptr) {
           if (ddy.thresh) {
             float m[4];
@@ -235,8 +235,9 @@ extern "C" size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols) {
   return (size_t)ceil_div(rows, NB_ROWS) * cols * sizeof(float);
 }
 
-extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float* dres, const float* x1, const float* rstd,
-                                     const float* w, float* dx1, void* dy_bf16, float* dw, int rows, int cols,
+extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int dres_dtype, const float* x1,
+                                     const float* rstd, const float* w, void* dx1, int dx1_dtype, void* dy_bf16,
+                                     float* dw, int rows, int cols,
                                      float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
                                      int out_drop, void* workspace, size_t workspace_bytes, void* stream) {
   MR_CHECK_ARG(dw == nullptr || (workspace && workspace_bytes >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols)),
@@ -246,21 +247,36 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const float
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
   DropCfg dy = make_drop(p_drop, seed, stream_y), dn = make_drop(p_drop, seed, stream_out);
-#define LAUNCH2(NV, TG)                                                                                           \
-  hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG>), dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0,        \
-                     (hipStream_t)stream, (const TG*)dxn, dres, x1, rstd, w, dx1, (bf16_t*)dy_bf16, dw_part, rows,    \
-                     cols, dy, dn, out_drop)
+#define LAUNCH3(NV, TG, TRI, TRO)                                                                                 \
+  hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG, TRI, TRO>), dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0, \
+                     (hipStream_t)stream, (const TG*)dxn, (const TRI*)dres, x1, rstd, w, (TRO*)dx1, (bf16_t*)dy_bf16,  \
+                     dw_part, rows, cols, dy, dn, out_drop)
+#define LAUNCH2(NV, TG) LAUNCH3(NV, TG, float, float)
 #define LAUNCH(NV)                                       \
   do {                                                   \
     if (dxn_dtype == MRMT3_BF16) LAUNCH2(NV, bf16_t);    \
     else LAUNCH2(NV, float);                             \
   } while (0)
-  if (cols == 512) LAUNCH(2);
+  const bool ri16 = dres != nullptr && dres_dtype == MRMT3_BF16, ro16 = dx1_dtype == MRMT3_BF16;
+  if (ri16 || ro16) {
+    // bf16 residual-gradient stream (the engine's bf16 path): model width 512 only
+    MR_CHECK_ARG(cols == 512, "add_rmsnorm_bwd: a bf16 residual gradient needs cols == 512");
+    if (dxn_dtype == MRMT3_BF16) {
+      if (ri16 && ro16) LAUNCH3(2, bf16_t, bf16_t, bf16_t);
+      else if (ri16) LAUNCH3(2, bf16_t, bf16_t, float);
+      else LAUNCH3(2, bf16_t, float, bf16_t);
+    } else {
+      if (ri16 && ro16) LAUNCH3(2, float, bf16_t, bf16_t);
+      else if (ri16) LAUNCH3(2, float, bf16_t, float);
+      else LAUNCH3(2, float, float, bf16_t);
+    }
+  } else if (cols == 512) LAUNCH(2);
   else if (cols == 256) LAUNCH(1);
   else if (cols == 1024) LAUNCH(4);
   else LAUNCH(8);
 #undef LAUNCH
 #undef LAUNCH2
+#undef LAUNCH3
   MR_CHECK_LAUNCH("add_rmsnorm_bwd");
   if (dw) {
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)ceil_div(cols, 64), 16), dim3(256), 0, (hipStream_t)stream,

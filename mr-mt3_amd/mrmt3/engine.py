@@ -58,6 +58,10 @@ class Engine:
         # overlap the attention / dgrad kernels of the layers below (their outputs are only needed by
         # the optimizer / the gradient exchange)
         self.overlap_wgrad = os.environ.get("MRMT3_WGRAD_STREAM", "1") != "0"
+        # residual-stream GRADIENT of the bf16 path: bf16 between the norm-backward sites of a stack (f32 at both
+        # ends) halves the largest streams of the backward row kernels; the forward residual stays f32
+        self.res_grad_dtype = (torch.bfloat16 if compute_dtype == torch.bfloat16 and
+                               os.environ.get("MRMT3_RES_GRAD", "bf16") == "bf16" else torch.float32)
         self._side = None
         self._held = []
 
@@ -182,9 +186,10 @@ class Engine:
         B, L, Le, enc, p = fin["B"], fin["L"], fin["Le"], fin["enc"], fin["p"]
         H, inner, seed = self.H, self.inner, self.seed
         has_y = n_layers > 0
+        rg = self.res_grad_dtype if has_y else torch.float32
         dx, dy = lib.add_rmsnorm_bwd(d_out, None, fin["x1"], fin["rstd"], self.ln(f"{prefix}.final_layer_norm.weight"),
                                      f.grad(f"{prefix}.final_layer_norm.weight"), want_dy=has_y, p=p, seed=seed,
-                                     stream_y=fin["s_in"], stream_out=fin["s_out"], out_drop=True)
+                                     stream_y=fin["s_in"], stream_out=fin["s_out"], out_drop=True, dx1_dtype=rg)
         for i in reversed(range(n_layers)):
             b = f"{prefix}.block.{i}.layer"
             t = tape.pop()
@@ -226,9 +231,10 @@ class Engine:
                          seed=seed, stream_id=t["s_att"])
             self.wgrad(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"))
             dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
+            last = i == 0                                     # the stack's input gradient leaves in f32
             dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
                                          f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed,
-                                         stream_y=t["s_in"], dx1=dx)
+                                         stream_y=t["s_in"], dx1=None if (last and dx.dtype != torch.float32) else dx)
             if on_layer_done is not None:
                 on_layer_done(prefix, i)
         return dx

@@ -32,7 +32,7 @@ _SIGS = {
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
     "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
     "mrmt3_add_rmsnorm_bwd_workspace_bytes": (csz, [ci, ci]),
-    "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp, csz, vp]),
+    "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp, csz, vp]),
     "mrmt3_attn_fwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
     "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
                             ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
@@ -240,16 +240,19 @@ def add_rmsnorm_fwd(x0, y, w, eps, xn_dtype, write_x1=True, p=0.0, seed=0, strea
 
 
 def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, stream_y=0, stream_out=0,
-                    out_drop=False, dx1=None):
+                    out_drop=False, dx1=None, dx1_dtype=torch.float32):
+    """`dres` and the returned dx1 may be f32 or bf16 (the bf16 engine's residual-gradient stream); `dx1=`
+    reuses a buffer (in place when it is `dres` itself)."""
     _dev(dxn, x1, rstd, w)
     rows, cols = x1.shape
     if dx1 is None:
-        dx1 = torch.empty_like(x1)
+        dx1 = torch.empty(rows, cols, device=x1.device, dtype=dx1_dtype)
     dy = torch.empty(rows, cols, device=x1.device, dtype=torch.bfloat16) if want_dy else None
     ws = workspace(load().mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols), x1.device)
-    _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _dt(dxn), _p(dres), _p(x1), _p(rstd), _p(w), _p(dx1), _p(dy), _p(dw), rows,
-                                        cols, p, seed, stream_y, stream_out, int(out_drop), _p(ws), ws.numel(),
-                                        _stream()), "add_rmsnorm_bwd")
+    _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _dt(dxn), _p(dres), _dt(dres) if dres is not None else F32, _p(x1),
+                                        _p(rstd), _p(w), _p(dx1), _dt(dx1), _p(dy), _p(dw), rows, cols, p, seed,
+                                        stream_y, stream_out, int(out_drop), _p(ws), ws.numel(), _stream()),
+           "add_rmsnorm_bwd")
     return dx1, dy
 
 
