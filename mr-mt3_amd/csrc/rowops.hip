@@ -300,54 +300,65 @@ __device__ __forceinline__ void gelu_new_fd(float x, float* f, float* d) {
   *d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
+// Both kernels move 8 elements (two dropout quads) per thread and iteration: 16-byte accesses for bf16.
 template <typename T>
 __global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ g, int rows, int dff, DropCfg d) {
-  const size_t n4 = (size_t)rows * dff / 4;
-  const int dff4 = dff / 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t row = i / dff4;
-    const int col = (int)(i % dff4) * 4;
-    float a[4], b[4], o[4];
+  const size_t n8 = (size_t)rows * dff / 8;
+  const int dff8 = dff / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / dff8;
+    const int col = (int)(i % dff8) * 8;
+    float a[8], b[8], o[8];
     load4<T>(h + row * 2 * dff + col, a);
+    load4<T>(h + row * 2 * dff + col + 4, a + 4);
     load4<T>(h + row * 2 * dff + dff + col, b);
+    load4<T>(h + row * 2 * dff + dff + col + 4, b + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = gelu_new_f(a[e]) * b[e];
+    for (int e = 0; e < 8; ++e) o[e] = gelu_new_f(a[e]) * b[e];
     if (d.thresh) {
-      float m[4];
-      drop_mask4(d, i, m);
+      float m[8];
+      drop_mask4(d, 2 * i, m);
+      drop_mask4(d, 2 * i + 1, m + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] *= m[e];
+      for (int e = 0; e < 8; ++e) o[e] *= m[e];
     }
     store4<T>(g + row * dff + col, o);
+    store4<T>(g + row * dff + col + 4, o + 4);
   }
 }
 
 __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ dg, bf16_t* __restrict__ dh,
                                  int rows, int dff, DropCfg d) {
-  const size_t n4 = (size_t)rows * dff / 4;
-  const int dff4 = dff / 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t row = i / dff4;
-    const int col = (int)(i % dff4) * 4;
-    float a[4], b[4], go[4], da[4], db[4];
+  const size_t n8 = (size_t)rows * dff / 8;
+  const int dff8 = dff / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / dff8;
+    const int col = (int)(i % dff8) * 8;
+    float a[8], b[8], go[8], da[8], db[8];
     load4<bf16_t>(h + row * 2 * dff + col, a);
+    load4<bf16_t>(h + row * 2 * dff + col + 4, a + 4);
     load4<bf16_t>(h + row * 2 * dff + dff + col, b);
+    load4<bf16_t>(h + row * 2 * dff + dff + col + 4, b + 4);
     load4<bf16_t>(dg + row * dff + col, go);
+    load4<bf16_t>(dg + row * dff + col + 4, go + 4);
     if (d.thresh) {
-      float m[4];
-      drop_mask4(d, i, m);
+      float m[8];
+      drop_mask4(d, 2 * i, m);
+      drop_mask4(d, 2 * i + 1, m + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) go[e] *= m[e];
+      for (int e = 0; e < 8; ++e) go[e] *= m[e];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 8; ++e) {
       float f, fd;
       gelu_new_fd(a[e], &f, &fd);
       da[e] = go[e] * b[e] * fd;
       db[e] = go[e] * f;
     }
     store4<bf16_t>(dh + row * 2 * dff + col, da);
+    store4<bf16_t>(dh + row * 2 * dff + col + 4, da + 4);
     store4<bf16_t>(dh + row * 2 * dff + dff + col, db);
+    store4<bf16_t>(dh + row * 2 * dff + dff + col + 4, db + 4);
   }
 }
 
@@ -358,9 +369,9 @@ static inline int ew_blocks(size_t n_items) {
 
 extern "C" int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop, uint64_t seed,
                                uint32_t stream_id, void* stream) {
-  MR_CHECK_ARG(h && g && rows > 0 && dff % 4 == 0, "geglu_fwd: bad args");
+  MR_CHECK_ARG(h && g && rows > 0 && dff % 8 == 0, "geglu_fwd: bad args");
   DropCfg d = make_drop(p_drop, seed, stream_id);
-  const int blocks = ew_blocks((size_t)rows * dff / 4);
+  const int blocks = ew_blocks((size_t)rows * dff / 8);
   if (dtype == MRMT3_BF16)
     hipLaunchKernelGGL(geglu_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (bf16_t*)g, rows, dff, d);
@@ -373,9 +384,9 @@ extern "C" int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dt
 
 extern "C" int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
                                uint64_t seed, uint32_t stream_id, void* stream) {
-  MR_CHECK_ARG(h && dg && dh && rows > 0 && dff % 4 == 0, "geglu_bwd: bad args");
+  MR_CHECK_ARG(h && dg && dh && rows > 0 && dff % 8 == 0, "geglu_bwd: bad args");
   DropCfg d = make_drop(p_drop, seed, stream_id);
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks((size_t)rows * dff / 4)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)h, (const bf16_t*)dg, (bf16_t*)dh, rows, dff, d);
   MR_CHECK_LAUNCH("geglu_bwd");
   return MRMT3_OK;
