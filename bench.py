@@ -103,8 +103,33 @@ def cpu_baseline(seconds):
         if time.perf_counter() - t0 > seconds or n >= 64:
             break
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="segments/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d x (log-mel + fwd + CE + bwd) of 1 segment (no optimizer, no dropout), fp32 torch CPU oracle, %.1f s" % (n, dt))
+    out = dict(value=n / dt, unit="segments/s", cores=torch.get_num_threads(), kind="port",
+               sample="%d x (log-mel + fwd + CE + bwd) of 1 segment (no optimizer, no dropout), fp32 torch CPU oracle, %.1f s" % (n, dt))
+    # per-stage figures of the same port: a few repetitions each, bounded to a few seconds
+    def best(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return min(ts)
+    sd_ng = {k: v.detach() for k, v in sd.items()}
+    mel1 = torch.from_numpy(logmel_ref.logmel_segments(audio))
+    with torch.no_grad():
+        stages = {
+            "log_mel_ms_per_segment": 1e3 * best(lambda: logmel_ref.logmel_segments(audio), 3),
+            "fwd_loss_ms_per_segment": 1e3 * best(lambda: t5_ref.ce_loss(t5_ref.forward_logits(sd_ng, T5_SMALL, mel1, lab), lab), 2),
+            # the reference's own decode algorithm (no KV cache, full prefix recompute), 64 tokens, 1 segment
+            "greedy_no_cache_64_tokens_s": best(lambda: t5_ref.generate_t5(sd_ng, T5_SMALL, mel1, max_length=64), 1),
+        }
+    stages["rtf_no_cache_64_tokens"] = stages["greedy_no_cache_64_tokens_s"] / SEG_SECONDS
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        out["cpu_model"] = "unknown"
+    out["stages"] = stages
+    return out
 
 
 def inference_rtf(dev, tokens, batch):
