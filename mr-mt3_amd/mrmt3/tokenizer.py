@@ -101,8 +101,53 @@ class Tokenizer:
         current = [0, 0]
         return np.asarray([int(e) for e in events if not self._is_repeat(int(e), current)], dtype=np.int64)
 
-    def targets_for_crop(self, feats: dict):
+    def randomize_tokens(self, events, rng=None) -> np.ndarray:
+        """Token-order augmentation (`randomize_tokens`, :425-457): between two consecutive shift tokens the note
+        groups — [program, velocity, pitch] or, for drums, [velocity, drum] — are put in a random order
+        (`np.random.shuffle` of the group indices, same draw as the reference).  Everything before the first shift
+        (the tie section) and from the last shift on is left alone.  Shift tokens are ids 0..999 as in the
+        reference's `get_token_name` (id 1000, a full 10 s shift, is not treated as one there either)."""
+        rng = rng or np.random
+        ev = [int(e) for e in events]
+        p_lo, p_hi = self.codec.event_type_range("program")
+        v_lo, v_hi = self.codec.event_type_range("velocity")
+        shifts = [i for i, e in enumerate(ev) if 0 <= e < 1000]
+        if not shifts:
+            return np.asarray(ev, dtype=np.int64)
+        out = ev[:shifts[0]]
+        for a, b in zip(shifts, shifts[1:]):
+            out.append(ev[a])
+            span, groups, k = ev[a + 1:b], [], 0
+            while k < len(span):
+                if p_lo <= span[k] <= p_hi:
+                    n = 3
+                elif v_lo <= span[k] <= v_hi:
+                    n = 2
+                else:
+                    n = 1        # the reference would spin forever here; such spans do not occur after tokenisation
+                groups.append(span[k:k + n])
+                k += n
+            order = np.arange(len(groups))
+            rng.shuffle(order)
+            for g in order:
+                out.extend(groups[g])
+        out.extend(ev[shifts[-1]:])
+        return np.asarray(out, dtype=np.int64)
+
+    def row_targets(self, feats: dict, start_frame: int, n_frames: int, rng=None) -> np.ndarray:
+        """The target pipeline of `__getitem__` (:403-414) for one row: extract (+ tie section), run-length encode,
+        and with `is_randomize_tokens` shuffle the note groups and only then drop repeated program / velocity tokens."""
+        row = self.run_length_encode_shifts(self.extract_target_sequence(feats, start_frame, n_frames))
+        if self.is_randomize_tokens:
+            row = self.remove_redundant_tokens(self.randomize_tokens(row, rng))
+        return row
+
+    def targets_for_crop(self, feats: dict, rng=None):
         """`(start_frame, n_frames) -> token ids` for `mrmt3.batching.DeviceBatcher.build`."""
-        def fn(start_frame, n_frames):
-            return self.run_length_encode_shifts(self.extract_target_sequence(feats, start_frame, n_frames))
-        return fn
+        return lambda start_frame, n_frames: self.row_targets(feats, start_frame, n_frames, rng)
+
+
+def collate_fn(lst):
+    """dataset_2_random.py:496-499: every item is already a [rows, ...] block; blocks are concatenated."""
+    import torch
+    return torch.cat([k[0] for k in lst]), torch.cat([k[1] for k in lst])

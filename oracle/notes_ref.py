@@ -291,3 +291,61 @@ def rle_shifts(events, max_shift=1000):
                     shift_steps -= o
             out.append(int(event))
     return np.array(out, dtype=np.int64)
+
+
+def token_name(idx):
+    """dataset_2_random.py:459-475."""
+    idx = int(idx)
+    if 1001 <= idx <= 1128: return f"pitch_{idx - 1001}"
+    if 1129 <= idx <= 1130: return f"velocity_{idx - 1129}"
+    if idx == 1131: return "tie"
+    if 1132 <= idx <= 1259: return f"program_{idx - 1132}"
+    if 1260 <= idx <= 1387: return f"drum_{idx - 1260}"
+    if 0 <= idx < 1000: return f"shift_{idx}"
+    return f"invalid_{idx}"
+
+
+def token_index(name):
+    kind, val = name.split("_")[0], name.split("_")[1] if "_" in name else "0"
+    return {"pitch": 1001, "velocity": 1129, "tie": 1131, "program": 1132, "drum": 1260, "shift": 0}[kind] + \
+        (0 if kind == "tie" else int(val))
+
+
+def randomize_tokens(token_lst, rng=np.random):
+    """dataset_2_random.py:425-457 on token NAMES, as the reference does it."""
+    shift_idx = [i for i in range(len(token_lst)) if "shift" in token_lst[i]]
+    if len(shift_idx) == 0:
+        return token_lst
+    res = token_lst[:shift_idx[0]]
+    for j in range(len(shift_idx) - 1):
+        res += [token_lst[shift_idx[j]]]
+        cur = token_lst[shift_idx[j] + 1:shift_idx[j + 1]]
+        cur_lst, ptr = [], 0
+        while ptr < len(cur):
+            t = cur[ptr]
+            if "program" in t:
+                cur_lst.append([cur[ptr], cur[ptr + 1], cur[ptr + 2]])
+                ptr += 3
+            elif "velocity" in t:
+                cur_lst.append([cur[ptr], cur[ptr + 1]])
+                ptr += 2
+        indices = np.arange(len(cur_lst))
+        rng.shuffle(indices)
+        res += [item for idx in indices for item in cur_lst[idx]]
+    res += token_lst[shift_idx[-1]:]
+    return res
+
+
+def remove_redundant(events):
+    ranges = [type_range("velocity"), type_range("program")]
+    cur, out = [0, 0], []
+    for event in events:
+        red = False
+        for i, (lo, hi) in enumerate(ranges):
+            if lo <= event <= hi:
+                if cur[i] == event:
+                    red = True
+                cur[i] = event
+        if not red:
+            out.append(int(event))
+    return np.array(out, dtype=np.int64)

@@ -113,3 +113,27 @@ def test_round_trip_through_the_decoder(seed):
     # onsets, pitches and programs survive exactly; offsets to the 10 ms grid
     assert [w[0::2] for w in want] == [h[0::2] for h in have]
     assert sum(abs(w[1] - h[1]) for w, h in zip(want, have)) == 0
+
+
+def test_token_order_augmentation_matches_reference_procedure():
+    """is_randomize_tokens: rows keep every program / velocity token, note groups between shifts are shuffled with the
+    same np.random draws as the reference's name-based procedure, repeats are dropped afterwards."""
+    tk = Tokenizer(is_randomize_tokens=True)
+    ns = _random_notes(7, n=80, dur=6.0)
+    feats = tk.tokenize(ns, int(6.5 * 16000))
+    plain = tk.run_length_encode_shifts(tk.extract_target_sequence(feats, 0, 256))
+    names = [ref.token_name(t) for t in plain]
+    want = ref.remove_redundant(np.array([ref.token_index(n) for n in ref.randomize_tokens(list(names), np.random.RandomState(11))]))
+    got = tk.row_targets(feats, 0, 256, rng=np.random.RandomState(11))
+    np.testing.assert_array_equal(got, want)
+    # the shuffle permutes groups inside a span: the multiset of (velocity?, pitch/drum) tokens per span is unchanged
+    shuffled = tk.randomize_tokens(plain, np.random.RandomState(3))
+    assert sorted(shuffled.tolist()) == sorted(plain.tolist()) and not np.array_equal(shuffled, plain)
+    # everything up to the first shift (the tie section) and from the last shift on is untouched
+    first = next(i for i, t in enumerate(plain) if t < 1000)
+    last = max(i for i, t in enumerate(plain) if t < 1000)
+    np.testing.assert_array_equal(shuffled[:first + 1], plain[:first + 1])
+    np.testing.assert_array_equal(shuffled[last:], plain[last:])
+    # names <-> ids
+    assert [ref.token_index(ref.token_name(i)) for i in (0, 5, 999, 1001, 1128, 1129, 1130, 1131, 1132, 1259, 1260, 1387)] == \
+        [0, 5, 999, 1001, 1128, 1129, 1130, 1131, 1132, 1259, 1260, 1387]
