@@ -6,20 +6,23 @@
 //   NT  C[M,N]   = A[M,K]  . B[N,K]^T     y = x W^T ; dx = dy (W^T)^T with W^T kept pre-transposed
 //   TN  C[N1,N2] = A[M,N1]^T . B[M,N2]    dW = dy^T x, reduction over the M (token) rows
 //
-// NT kernel: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4
-// v_mfma_f32_16x16x32_bf16 tiles), K step = 128 bytes of each row (64 bf16 / 32 f32), operands
-// staged HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write: the
-// register-staged version was LDS-write bound), double-buffered, one barrier per K step.  LDS rows
-// are 128 B with the 16-B chunk index XOR-ed by (row & 7): the LDS image of a wave-instruction is
-// linear (lane x 16 B), so the swizzle is applied to each lane's SOURCE address and again on the
-// ds_read_b128 fragment reads, which are conflict-free.  Workgroup ids are remapped so the 8 XCDs each walk a contiguous run of
-// (m-tile, n-tile) pairs and an A row-panel stays in one XCD's L2.
-// f32 inputs use v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) on the same LDS image.
+// NT kernel (gemm_nt_kernel, templated on the wave grid): a wave owns a 64x64 output sub-tile = 4x4
+// v_mfma_f32_16x16x32_bf16 tiles; two instantiations are launched — 256x256 (16 waves, 2 x 64 KiB stages of
+// 128-B K-steps, one workgroup per CU) when N is a multiple of 256, 256x128 (8 waves, 3 x 24 KiB stages of
+// 64-B K-steps, two workgroups per CU) otherwise.  Operands are staged L2 -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write: the register-staged version was LDS-write bound)
+// behind raw s_barrier + counted vmcnt.  The LDS image of a wave-instruction is linear (lane x 16 B), so the
+// bank swizzle is applied to each lane's SOURCE address and again on the ds_read_b128 fragment reads, which are
+// conflict-free.  Workgroup ids are remapped so the 8 XCDs each walk a contiguous run of (m-tile, n-tile) pairs
+// and an A row-panel stays in one XCD's L2; the epilogue transposes each wave's tile through the idle staging
+// LDS and stores whole rows with 16 bytes per lane.  f32 inputs use v_mfma_f32_16x16x4_f32 (exact f32 FMA
+// chains) on the same LDS image.
 //
 // TN kernel: 128x128 tile of dW per workgroup, 64 token rows per step; operand tiles are stored
 // row-major [64][128] (256-B rows, 32-B units XOR-swizzled by row & 7, again via the glds source
-// address) and consumed through ds_read_b64_tr_b16 (hardware transpose) so both MFMA operands get their 8 consecutive reduction indices per lane; the token
-// range is split over workgroups into f32 slabs that a second kernel sums in a fixed order
+// address) and consumed through ds_read_b64_tr_b16 (hardware transpose) so both MFMA operands get their 8
+// consecutive reduction indices per lane; the token range is split over workgroups — a split count that fills
+// whole resident waves of 512 workgroups — into f32 slabs that a second kernel sums in a fixed order
 // (bitwise reproducible, no atomics).
 #include "common.h"
 
