@@ -11,9 +11,12 @@
 //   then       final norm + lm_head gemv -> argmax / EOS bookkeeping / next-token embedding.
 // The step index and the finished flags live in device memory, so replays need no host
 // interaction; the host polls an 12-byte status block only when it wants to stop early.
-// Decode is latency/cache-bandwidth bound: every kernel reads its weight rows once with 16-byte
-// loads straight to registers (no LDS round trip for data used once), B<=8 sequences share each
-// weight read, and the 45.6 MB (bf16) of per-step weights stay resident in the 256 MB Infinity Cache.
+// A step is a chain of dependent launches (1.77 us each at best on this runtime), so every kernel is built to be
+// short rather than frugal: up to 8 sequences run one weight row x one sequence per wave (batch on gridDim.y;
+// the re-read of a weight row by the other sequences is an L2 hit), larger batches (<= 64) multiply 16 rows by
+// 16 sequences on the matrix cores with K split over a workgroup; the 45.6 MB (bf16) of per-step weights stay
+// resident in the 256 MB Infinity Cache.  mrmt3_decoder_set_prefix feeds memory rows before the start token
+// (the V1 segment-memory decode).
 #include "common.h"
 
 #define DMODEL 512
