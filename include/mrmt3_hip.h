@@ -138,10 +138,13 @@ int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, 
 int mrmt3_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* x, int rows,
                     int seq_len, int d, int vocab, int shift, int start_id, int pad_id,
                     int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
-/* dtable[id] += dropmask(dx[row])   (f32 atomics) */
+/* dtable[id] += dropmask(dx[row]).  No atomics: rows are ranked by id (counting sort), summed in sorted order and
+ * every table row has one writer, so the result is bitwise reproducible and insensitive to how skewed the ids are.
+ * workspace >= mrmt3_embed_bwd_workspace_bytes(rows, vocab, d); vocab <= 16384. */
+size_t mrmt3_embed_bwd_workspace_bytes(int rows, int vocab, int d);
 int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtable, int rows, int seq_len, int d,
                     int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed,
-                    uint32_t stream_id, void* stream);
+                    uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream);
 /* x[rows][d] f32 = src[rows][d] (src_dtype) + pos[(row % seq_len)+pos_offset], then dropout
  * (the encoder side of models/t5.py:596-601, input = proj(mel)); backward is dropmask only. */
 int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos, float* x, int rows, int seq_len,

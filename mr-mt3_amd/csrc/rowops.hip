@@ -439,30 +439,171 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
-                                                        float* __restrict__ dtable, int rows, int seq_len, int d,
-                                                        int vocab, int shift, int start_id, int pad_id, DropCfg dc) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+// ---- embedding gradient: dtable[id] += dropmask(dx[row]) without atomics -------------------------------------
+// Token ids of a transcription target are heavily skewed (a handful of velocity / program ids, and every padded
+// position maps to id 0), so a scatter-add with f32 atomics serialises on a few table rows and is order-dependent.
+// Instead the rows are ranked by id with a counting sort (per-workgroup histograms -> column scan -> stable
+// scatter), chunks of EB_CHUNK sorted rows are summed run by run, and the runs that cross a chunk boundary are
+// combined per id in chunk order: every table row has one writer and the result is bitwise reproducible.
+#define EB_ROWS 256     // rows ranked per workgroup
+#define EB_CHUNK 32     // sorted rows summed per workgroup
+struct EbPlan { int n_wg, n_chunk; size_t off_hist, off_base, off_order, off_tok, off_part, total; };
+static EbPlan eb_plan(int rows, int vocab, int d) {
+  EbPlan p;
+  p.n_wg = ceil_div(rows, EB_ROWS);
+  p.n_chunk = ceil_div(rows, EB_CHUNK);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+  p.off_hist = take((size_t)p.n_wg * vocab * 4);          // [n_wg][vocab] counts, then exclusive offsets inside an id
+  p.off_base = take((size_t)(vocab + 1) * 4);             // first sorted position of every id
+  p.off_order = take((size_t)rows * 4);                   // sorted position -> row
+  p.off_tok = take((size_t)rows * 4);                     // row -> id
+  p.off_part = take((size_t)p.n_chunk * 2 * d * 4);       // [chunk][first|last run][d] partial sums
+  p.total = o;
+  return p;
+}
+
+__global__ __launch_bounds__(EB_ROWS) void eb_hist_kernel(const int64_t* __restrict__ ids, int* __restrict__ tok,
+                                                           int* __restrict__ hist, int rows, int seq_len, int vocab,
+                                                           int shift, int start_id, int pad_id) {
+  extern __shared__ int h[];
+  for (int v = threadIdx.x; v < vocab; v += EB_ROWS) h[v] = 0;
+  __syncthreads();
+  const int row = blockIdx.x * EB_ROWS + threadIdx.x;
+  if (row < rows) {
+    const int id = (int)token_at(ids, row, seq_len, shift, start_id, pad_id, vocab);
+    tok[row] = id;
+    atomicAdd(&h[id], 1);                                   // LDS counter: only the count matters here
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < vocab; v += EB_ROWS) hist[(size_t)blockIdx.x * vocab + v] = h[v];
+}
+
+// per id: exclusive scan of the workgroup counts (in place) and the id's total.  A workgroup owns 32 ids; the
+// n_wg counts of an id are cut into 8 segments scanned by 8 threads (sum, scan of the 8 sums in LDS, rescan).
+__global__ __launch_bounds__(256) void eb_scan_wg_kernel(int* __restrict__ hist, int* __restrict__ base, int n_wg, int vocab) {
+  __shared__ int seg_sum[8][32];
+  const int vi = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int v = blockIdx.x * 32 + vi;
+  const int per = ceil_div(n_wg, 8), g0 = sg * per, g1 = min(n_wg, g0 + per);
+  int s = 0;
+  if (v < vocab)
+    for (int g = g0; g < g1; ++g) s += hist[(size_t)g * vocab + v];
+  seg_sum[sg][vi] = s;
+  __syncthreads();
+  int run = 0;
+  for (int k = 0; k < sg; ++k) run += seg_sum[k][vi];
+  if (v >= vocab) return;
+  for (int g = g0; g < g1; ++g) {
+    const int c = hist[(size_t)g * vocab + v];
+    hist[(size_t)g * vocab + v] = run;
+    run += c;
+  }
+  if (sg == 7) base[v] = run;                               // totals for now
+}
+// exclusive scan of the totals over the ids (one workgroup; vocab is a few thousand at most)
+__global__ __launch_bounds__(1024) void eb_scan_ids_kernel(int* __restrict__ base, int vocab) {
+  __shared__ int part[1024];
+  const int per = ceil_div(vocab, 1024);
+  const int lo = threadIdx.x * per, hi = min(vocab, lo + per);
+  int s = 0;
+  for (int v = lo; v < hi; ++v) s += base[v];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 1024; ++i) { const int c = part[i]; part[i] = run; run += c; }
+    base[vocab] = run;
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int v = lo; v < hi; ++v) { const int c = base[v]; base[v] = run; run += c; }
+}
+
+__global__ __launch_bounds__(EB_ROWS) void eb_scatter_kernel(const int* __restrict__ tok, const int* __restrict__ hist,
+                                                              const int* __restrict__ base, int* __restrict__ order,
+                                                              int rows, int vocab) {
+  __shared__ int t[EB_ROWS];
+  const int row = blockIdx.x * EB_ROWS + threadIdx.x;
+  const int mine = row < rows ? tok[row] : -1;
+  t[threadIdx.x] = mine;
+  __syncthreads();
   if (row >= rows) return;
-  const int64_t id = token_at(ids, row, seq_len, shift, start_id, pad_id, vocab);
-  float* trow = dtable + (size_t)id * d;
-  const size_t base = (size_t)row * d;
-  for (int col = lane * 4; col < d; col += 256) {
-    float a[4];
-    load4<float>(dx + base + col, a);
-    if (dc.thresh) {
-      float m[4];
-      drop_mask4(dc, (base + col) >> 2, m);
+  int rank = 0;                                             // earlier rows of this workgroup with the same id: stable
+  for (int j = 0; j < (int)threadIdx.x; ++j) rank += (t[j] == mine);
+  order[base[mine] + hist[(size_t)blockIdx.x * vocab + mine] + rank] = row;
+}
+
+// one workgroup sums EB_CHUNK consecutive sorted rows run by run.  A run that starts and ends inside the chunk has
+// all of its id's rows here: it is added to the table directly.  The chunk's first and last run may continue in
+// the neighbouring chunks: their sums go to part[chunk][0 / 1] and eb_combine_kernel adds them per id.
+__global__ __launch_bounds__(256) void eb_sum_kernel(const int* __restrict__ order, const int* __restrict__ tok,
+                                                      const int* __restrict__ base, const float* __restrict__ dx,
+                                                      float* __restrict__ dtable, float* __restrict__ part, int rows,
+                                                      int d, DropCfg dc) {
+  __shared__ int srow[EB_CHUNK], sid[EB_CHUNK];
+  const int p0 = blockIdx.x * EB_CHUNK, n = min(EB_CHUNK, rows - p0);
+  if (threadIdx.x < n) {
+    const int r = order[p0 + threadIdx.x];
+    srow[threadIdx.x] = r;
+    sid[threadIdx.x] = tok[r];
+  }
+  __syncthreads();
+  for (int col = threadIdx.x * 4; col < d; col += 1024) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int run_start = 0;
+    for (int i = 0; i < n; ++i) {
+      float a[4];
+      const size_t at = (size_t)srow[i] * d + col;
+      load4<float>(dx + at, a);
+      if (dc.thresh) {
+        float m[4];
+        drop_mask4(dc, at >> 2, m);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] *= m[e];
+        for (int e = 0; e < 4; ++e) a[e] *= m[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += a[e];
+      if (i + 1 == n || sid[i + 1] != sid[i]) {             // the run [run_start, i] of id sid[i] ends here
+        const int id = sid[i];
+        const bool whole = base[id] >= p0 + run_start && base[id + 1] <= p0 + i + 1;   // all rows of the id are in it
+        float* dst = whole ? dtable + (size_t)id * d + col
+                           : part + ((size_t)blockIdx.x * 2 + (run_start == 0 ? 0 : 1)) * d + col;
+        if (whole) {
+          float o[4];
+          load4<float>(dst, o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += o[e];
+        }
+        store4<float>(dst, acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = 0.f;
+        run_start = i + 1;
+      }
     }
-    // rows after a target's EOS get exactly zero gradient (nothing that is scored depends on them) and
-    // they all carry the pad id: skipping zero quads keeps ~70 % of a Slakh-shaped batch from hammering
-    // one table row with no-op atomics
-    if (a[0] == 0.f && a[1] == 0.f && a[2] == 0.f && a[3] == 0.f) continue;
+  }
+}
+
+// ids whose rows span several chunks: add the chunks' partial sums in chunk order
+__global__ __launch_bounds__(128) void eb_combine_kernel(const int* __restrict__ base, const float* __restrict__ part,
+                                                          float* __restrict__ dtable, int d) {
+  const int id = blockIdx.x;
+  const int lo = base[id], hi = base[id + 1];
+  if (hi <= lo) return;
+  const int c0 = lo / EB_CHUNK, c1 = (hi - 1) / EB_CHUNK;
+  if (c0 == c1 && lo >= c0 * EB_CHUNK && hi <= (c0 + 1) * EB_CHUNK) return;      // a whole run: already in the table
+  for (int col = threadIdx.x * 4; col < d; col += 512) {
+    float acc[4];
+    load4<float>(dtable + (size_t)id * d + col, acc);
+    for (int c = c0; c <= c1; ++c) {
+      // in chunk c the id's run is the first one unless it starts inside the chunk
+      const int slot = (lo > c * EB_CHUNK) ? 1 : 0;
+      float a[4];
+      load4<float>(part + ((size_t)c * 2 + slot) * d + col, a);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(trow + col + e, a[e]);
+      for (int e = 0; e < 4; ++e) acc[e] += a[e];
+    }
+    store4<float>(dtable + (size_t)id * d + col, acc);
   }
 }
 
@@ -477,12 +618,31 @@ extern "C" int mrmt3_embed_fwd(const int64_t* ids, const float* table, const flo
   return MRMT3_OK;
 }
 
+extern "C" size_t mrmt3_embed_bwd_workspace_bytes(int rows, int vocab, int d) { return eb_plan(rows, vocab, d).total; }
+
 extern "C" int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtable, int rows, int seq_len, int d,
                                int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed,
-                               uint32_t stream_id, void* stream) {
-  MR_CHECK_ARG(ids && dx && dtable && rows > 0 && seq_len > 0 && d % 4 == 0, "embed_bwd: bad args");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids, dx,
-                     dtable, rows, seq_len, d, vocab, shift, start_id, pad_id, make_drop(p_drop, seed, stream_id));
+                               uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
+  MR_CHECK_ARG(ids && dx && dtable && workspace && rows > 0 && seq_len > 0 && d % 4 == 0 && vocab > 0,
+               "embed_bwd: bad args");
+  MR_CHECK_ARG(vocab * (int)sizeof(int) <= 64 * 1024, "embed_bwd: vocabulary too large for the LDS histogram");
+  const EbPlan P = eb_plan(rows, vocab, d);
+  MR_CHECK_ARG(workspace_bytes >= P.total, "embed_bwd: workspace too small");
+  unsigned char* ws = (unsigned char*)workspace;
+  int* hist = (int*)(ws + P.off_hist);
+  int* base = (int*)(ws + P.off_base);
+  int* order = (int*)(ws + P.off_order);
+  int* tok = (int*)(ws + P.off_tok);
+  float* part = (float*)(ws + P.off_part);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(eb_hist_kernel, dim3(P.n_wg), dim3(EB_ROWS), vocab * sizeof(int), s, ids, tok, hist, rows, seq_len,
+                     vocab, shift, start_id, pad_id);
+  hipLaunchKernelGGL(eb_scan_wg_kernel, dim3(ceil_div(vocab, 32)), dim3(256), 0, s, hist, base, P.n_wg, vocab);
+  hipLaunchKernelGGL(eb_scan_ids_kernel, dim3(1), dim3(1024), 0, s, base, vocab);
+  hipLaunchKernelGGL(eb_scatter_kernel, dim3(P.n_wg), dim3(EB_ROWS), 0, s, tok, hist, base, order, rows, vocab);
+  hipLaunchKernelGGL(eb_sum_kernel, dim3(P.n_chunk), dim3(256), 0, s, order, tok, base, dx, dtable, part, rows, d,
+                     make_drop(p_drop, seed, stream_id));
+  hipLaunchKernelGGL(eb_combine_kernel, dim3(vocab), dim3(128), 0, s, base, part, dtable, d);
   MR_CHECK_LAUNCH("embed_bwd");
   return MRMT3_OK;
 }

@@ -39,7 +39,8 @@ _SIGS = {
     "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, cu32, vp]),
     "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, cu32, vp]),
     "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
-    "mrmt3_embed_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_embed_bwd_workspace_bytes": (csz, [ci, ci, ci]),
+    "mrmt3_embed_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp, csz, vp]),
     "mrmt3_addpos_fwd": (ci, [vp, ci, vp, vp, ci, ci, ci, ci, cf, cu64, cu32, vp]),
     "mrmt3_dropmask_cast": (ci, [vp, vp, csz, cf, cu64, cu32, vp]),
     "mrmt3_ce_count": (ci, [vp, ci, ci, ci, ci, vp, vp]),
@@ -310,8 +311,9 @@ def embed_bwd(ids, dx, dtable, seq_len, shift, start_id=0, pad_id=0, p=0.0, seed
     _dev(ids, dx, dtable)
     rows = ids.numel()
     V, d = dtable.shape
+    ws = workspace(load().mrmt3_embed_bwd_workspace_bytes(rows, V, d), dx.device)
     _check(load().mrmt3_embed_bwd(_p(ids), _p(dx), _p(dtable), rows, seq_len, d, V, int(shift), start_id, pad_id, p,
-                                  seed, stream_id, _stream()), "embed_bwd")
+                                  seed, stream_id, _p(ws), ws.numel(), _stream()), "embed_bwd")
 
 
 def addpos_fwd(src, pos, seq_len, pos_offset=0, p=0.0, seed=0, stream_id=0):

@@ -385,6 +385,46 @@ def test_embed_shift_right_and_scatter(dev):
     assert torch.equal(lib.addpos_fwd(src, pos, L).view(B, L, d), src.view(B, L, d) + pos[None, :L])
 
 
+@pytest.mark.parametrize("skew", ["uniform", "padded", "one_id"])
+def test_embed_bwd_sorted_sum_is_exact_and_reproducible(dev, skew):
+    """The embedding gradient is a sorted segmented sum (no atomics): equals a float64 index_add to f32 rounding,
+    accumulates into what the table already holds, is bitwise identical across runs, for uniform ids, for
+    Slakh-shaped rows (most positions are padding -> id 0) and when every row carries the same id."""
+    from mrmt3 import lib
+    B, L, d, V = 16, 1024, 512, 1536
+    g = torch.Generator().manual_seed(5)
+    if skew == "uniform":
+        labels = torch.randint(3, 1391, (B, L), generator=g)
+    elif skew == "padded":
+        labels = torch.full((B, L), -100, dtype=torch.long)
+        for b in range(B):
+            n = int(torch.randint(50, 400, (1,), generator=g))
+            labels[b, :n] = torch.randint(1129, 1140, (n,), generator=g)       # a handful of hot ids
+            labels[b, n] = 1
+    else:
+        labels = torch.full((B, L), 7, dtype=torch.long)
+    labels = labels.to(dev)
+    dx = torch.randn(B * L, d, generator=g).to(dev)
+    ids = torch.cat([torch.zeros(B, 1, dtype=torch.long, device=dev), labels[:, :-1]], 1)
+    ids = ids.masked_fill(ids == -100, 0).view(-1)
+    start = torch.randn(V, d, generator=g).to(dev)
+    want = start.double().index_add_(0, ids, dx.double())
+    outs = []
+    for _ in range(2):
+        dt = start.clone()
+        lib.embed_bwd(labels, dx, dt, L, shift=True)
+        outs.append(dt)
+    assert torch.equal(outs[0], outs[1])
+    counts = torch.bincount(ids, minlength=V).double().clamp(min=1)
+    err = (outs[0].double() - want).abs().max(dim=1).values
+    assert (err <= 4e-6 * counts.sqrt() * 8 + 1e-5).all(), err.max().item()
+    # dropout: the kept elements are those of the forward mask stream (same seed / stream id), scaled by 1/(1-p)
+    dt = torch.zeros(V, d, device=dev)
+    lib.embed_bwd(labels, torch.ones(B * L, d, device=dev), dt, L, shift=True, p=0.25, seed=9, stream_id=4)
+    kept = dt.sum().item() / (B * L * d) * 0.75
+    assert abs(kept - 0.75) < 5e-3
+
+
 @pytest.mark.parametrize("weighted", [False, True])
 def test_cross_entropy(dev, weighted):
     from mrmt3 import lib
