@@ -126,9 +126,11 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
                                                               const float* __restrict__ x1, const float* __restrict__ rstd_in,
                                                               const float* __restrict__ w, TRO* __restrict__ dx1,
                                                               bf16_t* __restrict__ dy, float* __restrict__ dw_part, int rows,
-                                                              int cols, DropCfg ddy, DropCfg dout, int out_drop) {
+                                                              int cols, DropCfg ddy, DropCfg dout, int out_drop,
+                                                              int* __restrict__ dw_counters) {
   __shared__ float red[4 * 256 * NV];  // [wave][col]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (dw_counters != nullptr && blockIdx.x == 0 && (int)threadIdx.x < (cols + 63) / 64) dw_counters[threadIdx.x] = 0;
   constexpr int nv = NV;
   float dwp[NV][4];
   float wv[NV][4];
@@ -208,12 +210,16 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
       dw_part[(size_t)blockIdx.x * cols + c] = redf[c] + redf[cols + c] + redf[2 * cols + c] + redf[3 * cols + c];
 }
 
-// dw[c] += sum over partial rows.  grid = (cols/64, 16 row chunks); a thread = (column, 1 of 4 row
-// groups) streams its rows with independent loads, the workgroup combines through LDS and issues one
-// atomic per column (16 adders per address in total: far from the contended regime).
+// dw[c] += sum over partial rows.  grid = (cols/64, DW_CHUNKS row chunks); a thread = (column, 1 of 4 row
+// groups) streams its rows with independent loads, the workgroup combines through LDS and leaves its 64 sums in
+// scratch[chunk]; the chunk workgroup that finishes last (agent-scope counter, zeroed by the norm-backward
+// kernel before) adds the DW_CHUNKS partials in chunk order: no float atomics, bitwise reproducible.
+#define DW_CHUNKS 16
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                        int n_part, int cols) {
+                                                        int n_part, int cols, float* __restrict__ scratch,
+                                                        int* __restrict__ counters) {
   __shared__ float red[4][64];
+  __shared__ int last;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   const int per = (n_part + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = min(n_part, r0 + per);
@@ -228,11 +234,25 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
   }
   red[g][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
-  if (g == 0 && c < cols) atomicAdd(dw + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+  if (g == 0 && c < cols)
+    scratch[(size_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&counters[blockIdx.x], 1) == (int)gridDim.y - 1;
+  __syncthreads();
+  if (!last) return;
+  if (g == 0 && c < cols) {
+    float acc = dw[c];
+    for (int k = 0; k < (int)gridDim.y; ++k)
+      acc += __hip_atomic_load(&scratch[(size_t)k * cols + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dw[c] = acc;
+  }
+  if (threadIdx.x == 0) counters[blockIdx.x] = 0;
 }
 
 extern "C" size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols) {
-  return (size_t)ceil_div(rows, NB_ROWS) * cols * sizeof(float);
+  // per-workgroup partial rows | DW_CHUNKS chunk sums | one arrival counter per 64 columns
+  return ((size_t)ceil_div(rows, NB_ROWS) + DW_CHUNKS) * cols * sizeof(float) + (size_t)ceil_div(cols, 64) * sizeof(int);
 }
 
 extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int dres_dtype, const float* x1,
@@ -243,6 +263,8 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
   MR_CHECK_ARG(dw == nullptr || (workspace && workspace_bytes >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols)),
                "add_rmsnorm_bwd: workspace too small");
   float* dw_part = dw ? (float*)workspace : nullptr;
+  float* dw_scratch = dw ? dw_part + (size_t)ceil_div(rows, NB_ROWS) * cols : nullptr;
+  int* dw_counters = dw ? (int*)(dw_scratch + (size_t)DW_CHUNKS * cols) : nullptr;
   MR_CHECK_ARG(dxn && x1 && rstd && w && dx1, "add_rmsnorm_bwd: null pointer");
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
@@ -250,7 +272,7 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
 #define LAUNCH3(NV, TG, TRI, TRO)                                                                                 \
   hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG, TRI, TRO>), dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0, \
                      (hipStream_t)stream, (const TG*)dxn, (const TRI*)dres, x1, rstd, w, (TRO*)dx1, (bf16_t*)dy_bf16,  \
-                     dw_part, rows, cols, dy, dn, out_drop)
+                     dw_part, rows, cols, dy, dn, out_drop, dw_counters)
 #define LAUNCH2(NV, TG) LAUNCH3(NV, TG, float, float)
 #define LAUNCH(NV)                                       \
   do {                                                   \
@@ -279,8 +301,8 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
 #undef LAUNCH3
   MR_CHECK_LAUNCH("add_rmsnorm_bwd");
   if (dw) {
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)ceil_div(cols, 64), 16), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)dw_part, dw, ceil_div(rows, NB_ROWS), cols);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)ceil_div(cols, 64), DW_CHUNKS), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dw_part, dw, ceil_div(rows, NB_ROWS), cols, dw_scratch, dw_counters);
     MR_CHECK_LAUNCH("add_rmsnorm_bwd dw reduce");
   }
   return MRMT3_OK;
