@@ -182,7 +182,7 @@ int mrmt3_transpose(const void* in, int in_dtype, void* out, int out_dtype, int 
 int mrmt3_cast(const void* in, int in_dtype, void* out, int out_dtype, size_t n, void* stream);
 /* One launch transposes n_mats bf16 matrices living in two flat buffers.  desc_table: device array of
  * {int64 src_off, int64 dst_off, int32 rows, int32 cols} (element offsets; dst is [cols][rows]);
- * tile_start: device int32 prefix sums of ceil(rows/32)*ceil(cols/32), length n_mats. */
+ * tile_start: device int32 prefix sums of ceil(rows/64)*ceil(cols/64), length n_mats. */
 int mrmt3_transpose_batched(const void* src_bf16, void* dst_bf16, const void* desc_table,
                             const int* tile_start, int n_mats, int total_tiles, void* stream);
 

@@ -1025,26 +1025,51 @@ __global__ void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out
 
 // batched bf16 transpose of many small matrices described by a device table of
 // {src_off, dst_off, rows, cols} (element offsets) — one launch refreshes every pre-transposed weight.
+// 64x64 tiles; both sides move element PAIRS (4 bytes per lane, 128 contiguous bytes per 32 lanes) when the
+// matrix dimensions and offsets are even, single elements otherwise.
+#define TRB 64
 struct TrDesc { long long src, dst; int rows, cols; };
-__global__ void transpose_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                         const TrDesc* __restrict__ tab, const int* __restrict__ tile_start, int n_mats) {
-  __shared__ bf16_t tile[32][33];
-  // find the matrix this block belongs to (tile_start is a prefix sum of 32x32 tile counts)
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                                const TrDesc* __restrict__ tab,
+                                                                const int* __restrict__ tile_start, int n_mats) {
+  __shared__ bf16_t tile[TRB][TRB + 2];
+  // find the matrix this block belongs to (tile_start is a prefix sum of 64x64 tile counts)
   int m = 0;
   while (m + 1 < n_mats && (int)blockIdx.x >= tile_start[m + 1]) ++m;
   const TrDesc d = tab[m];
   const int local = blockIdx.x - tile_start[m];
-  const int tiles_x = (d.cols + 31) / 32;
-  const int bx = (local % tiles_x) * 32, by = (local / tiles_x) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int j = ty; j < 32; j += 8) {
-    const int r = by + j, c = bx + tx;
-    tile[j][tx] = (r < d.rows && c < d.cols) ? src[d.src + (size_t)r * d.cols + c] : (bf16_t)0;
+  const int tiles_x = (d.cols + TRB - 1) / TRB;
+  const int bx = (local % tiles_x) * TRB, by = (local / tiles_x) * TRB;
+  const int tp = threadIdx.x & 31, ty = threadIdx.x >> 5;      // pair index, 8 row groups
+  const bool even = ((d.rows | d.cols) & 1) == 0 && ((d.src | d.dst) & 1) == 0;
+  for (int j = ty; j < TRB; j += 8) {
+    const int r = by + j, c = bx + 2 * tp;
+    bf16_t v0 = 0, v1 = 0;
+    if (r < d.rows) {
+      const bf16_t* p = src + d.src + (size_t)r * d.cols + c;
+      if (even && c + 1 < d.cols) {
+        const unsigned u = *(const unsigned*)p;
+        v0 = (bf16_t)(u & 0xFFFFu);
+        v1 = (bf16_t)(u >> 16);
+      } else {
+        if (c < d.cols) v0 = p[0];
+        if (c + 1 < d.cols) v1 = p[1];
+      }
+    }
+    tile[j][2 * tp] = v0;
+    tile[j][2 * tp + 1] = v1;
   }
   __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    const int c = bx + j, r = by + tx;
-    if (r < d.rows && c < d.cols) dst[d.dst + (size_t)c * d.rows + r] = tile[tx][j];
+  for (int j = ty; j < TRB; j += 8) {
+    const int c = bx + j, r = by + 2 * tp;                    // output row c holds source rows r, r+1 side by side
+    if (c >= d.cols) continue;
+    bf16_t* q = dst + d.dst + (size_t)c * d.rows + r;
+    const bf16_t v0 = tile[2 * tp][j], v1 = tile[2 * tp + 1][j];
+    if (even && r + 1 < d.rows) *(unsigned*)q = (unsigned)v0 | ((unsigned)v1 << 16);
+    else {
+      if (r < d.rows) q[0] = v0;
+      if (r + 1 < d.rows) q[1] = v1;
+    }
   }
 }
 

@@ -164,7 +164,7 @@ class FlatParams:
                     continue  # the mel input needs no gradient
                 rec.append((o, self.t_offsets[name], r, c))
                 starts.append(tot)
-                tot += ((r + 31) // 32) * ((c + 31) // 32)
+                tot += ((r + 63) // 64) * ((c + 63) // 64)       # 64x64 tiles (csrc/rowops.hip TRB)
             tab = np.zeros(len(rec), dtype=[("src", "<i8"), ("dst", "<i8"), ("rows", "<i4"), ("cols", "<i4")])
             for i, t in enumerate(rec):
                 tab[i] = t

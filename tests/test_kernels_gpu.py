@@ -475,6 +475,31 @@ def test_transpose_cast(dev):
     assert torch.equal(c, w.view(-1).bfloat16())
 
 
+def test_transpose_batched_even_and_odd_shapes(dev):
+    """One launch, several matrices in flat buffers: pair-vectorised path (even dims / offsets) and the scalar
+    fallback (odd dims or offsets), tiles that overhang the matrix."""
+    import numpy as np
+    from mrmt3 import lib
+    shapes = [(384, 512), (70, 130), (33, 7), (64, 64), (5, 1000)]
+    src_parts, recs, starts, tot, so, do = [], [], [], 0, 0, 0
+    for r, c in shapes:
+        src_parts.append(torch.randn(r * c, device=dev).bfloat16())
+        recs.append((so, do, r, c))
+        starts.append(tot)
+        tot += ((r + 63) // 64) * ((c + 63) // 64)
+        so += r * c
+        do += r * c
+    src = torch.cat(src_parts)
+    dst = torch.zeros_like(src)
+    tab = np.zeros(len(recs), dtype=[("src", "<i8"), ("dst", "<i8"), ("rows", "<i4"), ("cols", "<i4")])
+    for i, t in enumerate(recs):
+        tab[i] = t
+    lib.transpose_batched(src, dst, torch.from_numpy(tab.view(np.uint8).copy()).to(dev),
+                          torch.tensor(starts, dtype=torch.int32, device=dev), len(recs), tot)
+    for (so_, do_, r, c) in recs:
+        assert torch.equal(dst[do_:do_ + r * c].view(c, r), src[so_:so_ + r * c].view(r, c).t())
+
+
 def test_errors_are_reported_not_fatal(dev):
     from mrmt3 import lib
     a = torch.randn(64, 40, device=dev).bfloat16()   # K*2 not a multiple of 64
