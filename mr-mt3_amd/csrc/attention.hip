@@ -269,33 +269,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams P) {
-  // one wave per (b, q) row; lane l covers 8 consecutive columns (16-byte loads), so a head's 64
-  // columns live in 8 consecutive lanes and reduce with three shuffles
-  const int lane = threadIdx.x & 63;
-  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*Lq + q
-  if (row >= (size_t)P.B * P.Lq) return;
-  const int b = (int)(row / P.Lq), q = (int)(row % P.Lq);
-  const int ncol = P.H * HD;
-  for (int c0 = 0; c0 < ncol; c0 += 512) {
-    const int col = c0 + lane * 8;
-    float a = 0.f;
-    if (col < ncol) {
-      const u32x4 x = *(const u32x4*)(P.d_o + row * P.lddo + col), y = *(const u32x4*)(P.o + row * P.ldo + col);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a = fmaf(__uint_as_float(x[e] << 16), __uint_as_float(y[e] << 16), a);
-        a = fmaf(__uint_as_float(x[e] & 0xFFFF0000u), __uint_as_float(y[e] & 0xFFFF0000u), a);
-      }
-    }
-    a += __shfl_xor(a, 1, 64);
-    a += __shfl_xor(a, 2, 64);
-    a += __shfl_xor(a, 4, 64);
-    if ((lane & 7) == 0 && col < ncol) P.delta[((size_t)b * P.H + (col >> 6)) * P.Lq + q] = a;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward: dK, dV.  workgroup = 128 keys (wave = 32 keys, key on the lane), loop over 32-query
 // blocks staged 3 blocks ahead (4 LDS stages of Q | dO | lse,delta)
 // ------------------------------------------------------------------------------------------------
