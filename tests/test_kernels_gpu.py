@@ -249,7 +249,8 @@ def _attn_ref(q, k, v, B, H, Lq, Lk, causal):
 
 
 ATTN_SHAPES = [(2, 6, 256, 256, False), (2, 6, 1024, 1024, True), (1, 6, 1024, 320, False),
-               (2, 3, 200, 72, False), (1, 2, 300, 300, True), (1, 6, 64, 1024, False), (1, 1, 1088, 1088, True)]
+               (2, 3, 200, 72, False), (1, 2, 300, 300, True), (1, 6, 64, 1024, False), (1, 1, 1088, 1088, True),
+               (1, 1, 1, 1, False), (1, 2, 129, 257, False), (1, 1, 33, 33, True), (1, 2, 2048, 2112, False)]
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", ATTN_SHAPES)
