@@ -136,6 +136,31 @@ def test_gemm_nt_bf16(dev, M, N, K):
     assert _rel(acc, ref + 1.0) < 1e-5
 
 
+def test_gemm_full_benchmark_sizes(dev):
+    """The batch-64 shapes of the benchmark step (65 536 token rows): NT against an f32 matmul on sampled rows, the
+    wgrad TN product in full, plus linearity (C(2A) == 2 C(A) exactly: powers of two commute with bf16 rounding)."""
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(1)
+    M = 65536
+    for N, K in ((2048, 512), (1152, 512), (512, 1024)):
+        a = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+        b = (torch.randn(N, K, generator=g) * 0.05).to(dev).bfloat16()
+        out = lib.gemm_nt(a, b)
+        rows = torch.randint(0, M, (512,), generator=g).to(dev)
+        ref = a[rows].float() @ b.float().t()
+        assert _rel(out[rows], ref) < 6e-3
+        assert torch.equal(lib.gemm_nt(a * 2, b), out * 2)
+    dy = (torch.randn(M, 1152, generator=g) * 0.1).to(dev).bfloat16()
+    x = torch.randn(M, 512, generator=g).to(dev).bfloat16()
+    dw = torch.zeros(1152, 512, device=dev)
+    lib.gemm_tn(dy, x, dw, accumulate=True)
+    ref = dy.float().t() @ x.float()
+    assert _rel(dw, ref) < 2e-3
+    dw2 = torch.zeros(1152, 512, device=dev)
+    lib.gemm_tn(dy, x, dw2, accumulate=True)
+    assert torch.equal(dw, dw2)                                    # fixed-order split-K: bitwise reproducible
+
+
 def test_gemm_nt_strided_and_asymmetric(dev):
     from mrmt3 import lib
     # A = I (padded) with an asymmetric B catches a transposed C write
