@@ -302,3 +302,26 @@ defaults:
         midi_io.read_midi(str(out / "run1" / f"Track{k:02d}" / "mix.mid"))          # a well-formed MIDI file
     assert "Onset F1" in scores and "Onset + program F1 (midi_class)" in scores
     assert all(0.0 <= v <= 1.0 for v in scores.values() if not isinstance(v, dict))
+
+
+def test_full_benchmark_batch_gradient_is_the_mean_of_its_halves(dev):
+    """BASELINE configs[1] at full size (64 segments x 1024 tokens, dropout off): the gradient of the batch equals
+    the mean of the gradients of its two halves (a size-independent property of the whole fwd+bwd path), and the
+    step is bitwise reproducible."""
+    from mrmt3.synthetic import synth_audio, synth_labels
+    from mrmt3.trainer import Trainer
+    m = _model("t5", dev, dropout_rate=0.0)
+    tr = Trainer(m, lr=0.0)
+    audio = torch.from_numpy(synth_audio(64, seed=8)).to(dev)
+    lab = torch.from_numpy(synth_labels(64, seed=9)).to(dev)
+    loss = tr.train_step(audio, lab, audio=True).item()
+    g_all = m.flat.G.clone()
+    tr.train_step(audio, lab, audio=True)
+    assert torch.equal(m.flat.G, g_all)
+    la = tr.train_step(audio[:32], lab[:32], audio=True).item()
+    g_a = m.flat.G.clone()
+    lb = tr.train_step(audio[32:], lab[32:], audio=True).item()
+    g_b = m.flat.G.clone()
+    assert abs(loss - (la + lb) / 2) < 2e-5
+    rel = ((g_all - (g_a + g_b) / 2).norm() / g_all.norm()).item()
+    assert rel < 3e-3, rel
