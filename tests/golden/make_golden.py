@@ -128,6 +128,7 @@ def sample_idx(shape, n, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true")
+    ap.add_argument("--lr", action="store_true", help="only record the reference's LR-schedule values")
     ap.add_argument("--param-order", action="store_true",
                     help="only record the reference models' parameters() order (optimizer-state indexing)")
     ap.add_argument("--v1-decode", action="store_true",
@@ -144,6 +145,24 @@ def main():
     prev = torch.from_numpy(synth_labels(B, full=False, seed=999))
     import torch.nn.functional as F
 
+    if args.lr:
+        import importlib.util
+        import json
+        spec = importlib.util.spec_from_file_location("reference_utils", "/root/reference/utils.py")
+        ru = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ru)
+        rec = []
+        for warm, total, min_lr in ((64500, 1289 * 800, 1e-4), (10, 100, 1e-4), (5, 50, 2e-5)):
+            opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=2e-4)
+            sch = ru.get_cosine_schedule_with_warmup(opt, warm, total, min_lr=min_lr)
+            steps = sorted(set([0, 1, 2, warm // 2, warm - 1, warm, warm + 1, (warm + total) // 2, total - 1, total, total + 7]))
+            lam = sch.lr_lambdas[0]
+            rec.append({"num_warmup_steps": warm, "num_training_steps": total, "min_lr": min_lr, "steps": steps,
+                        "multiplier": [float(lam(s)) for s in steps]})
+        with open(os.path.join(HERE, "lr_golden.json"), "w") as f:
+            json.dump(rec, f, indent=0)
+        print("wrote lr_golden.json", [len(r["steps"]) for r in rec])
+        return
     if args.param_order:
         import json
         rec = {}

@@ -106,3 +106,27 @@ def test_lr_schedule_matches_oracle():
     lam = cosine_warmup_lambda(64500, 1289 * 800, min_lr=1e-4)
     for s in (0, 1, 64499, 64500, 500000, 1031199, 1031200):
         assert lam(s) == t5_ref.cosine_lambda(s, 64500, 1289 * 800, min_lr=1e-4)
+
+
+def test_lr_schedule_matches_reference_values():
+    """utils.get_cosine_schedule_with_warmup against multipliers recorded from the reference's own utils.py
+    (tests/golden/lr_golden.json, make_golden.py --lr): warm-up, the step at the boundary, the min_lr floor on the
+    multiplier, and steps past the end (the cosine turns back up there, as in the reference)."""
+    import json
+    import os
+    import torch
+    from oracle import t5_ref
+    from utils import cosine_warmup_lambda, get_cosine_schedule_with_warmup
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr_golden.json")) as f:
+        rec = json.load(f)
+    for r in rec:
+        lam = cosine_warmup_lambda(r["num_warmup_steps"], r["num_training_steps"], min_lr=r["min_lr"])
+        for s, want in zip(r["steps"], r["multiplier"]):
+            assert lam(s) == want, (r, s)
+            assert t5_ref.cosine_lambda(s, r["num_warmup_steps"], r["num_training_steps"], min_lr=r["min_lr"]) == want
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=2e-4)
+    sch = get_cosine_schedule_with_warmup(opt, 10, 100, min_lr=1e-4)
+    assert sch.get_last_lr()[0] == 0.0                       # step 0 of the warm-up
+    opt.step()
+    sch.step()
+    assert abs(sch.get_last_lr()[0] - 2e-4 * rec[1]["multiplier"][1]) < 1e-18
