@@ -159,9 +159,21 @@ def main():
             lam = sch.lr_lambdas[0]
             rec.append({"num_warmup_steps": warm, "num_training_steps": total, "min_lr": min_lr, "steps": steps,
                         "multiplier": [float(lam(s)) for s in steps]})
+        # the two unused schedulers of the same file, for completeness of the utils surface
+        opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        noam = ru.get_noam_scheduler(opt, 4000, 512)
+        noam_lrs = []
+        for _ in range(6):
+            noam_lrs.append(float(noam.get_last_lr()[0]))
+            opt.step()
+            noam.step()
+        opt2 = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        lin = ru.get_mt3_optimizer(opt2, 8)
+        rec = {"cosine": rec, "noam_first_lrs": noam_lrs,
+               "mt3_linear_multiplier": [float(lin.lr_lambdas[0](s)) for s in range(12)]}
         with open(os.path.join(HERE, "lr_golden.json"), "w") as f:
             json.dump(rec, f, indent=0)
-        print("wrote lr_golden.json", [len(r["steps"]) for r in rec])
+        print("wrote lr_golden.json", [len(r["steps"]) for r in rec["cosine"]])
         return
     if args.param_order:
         import json

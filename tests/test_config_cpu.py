@@ -119,6 +119,18 @@ def test_lr_schedule_matches_reference_values():
     from utils import cosine_warmup_lambda, get_cosine_schedule_with_warmup
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr_golden.json")) as f:
         rec = json.load(f)
+    noam_want, lin_want, rec = rec["noam_first_lrs"], rec["mt3_linear_multiplier"], rec["cosine"]
+    from utils import get_mt3_optimizer, get_noam_scheduler, remove_state_dict_prefix
+    o = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    noam, got = get_noam_scheduler(o, 4000, 512), []
+    for _ in range(6):
+        got.append(float(noam.get_last_lr()[0]))
+        o.step()
+        noam.step()
+    assert got == noam_want
+    lin = get_mt3_optimizer(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1.0), 8)
+    assert [float(lin.lr_lambdas[0](s)) for s in range(12)] == lin_want
+    assert list(remove_state_dict_prefix({"module.a.module.b": 1, "c": 2})) == ["a.b", "c"]
     for r in rec:
         lam = cosine_warmup_lambda(r["num_warmup_steps"], r["num_training_steps"], min_lr=r["min_lr"])
         for s, want in zip(r["steps"], r["multiplier"]):
