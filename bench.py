@@ -231,6 +231,7 @@ def main():
         "final_loss": final_loss,
         "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
+        "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
     if not args.no_roofline:
         # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings.
