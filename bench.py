@@ -123,6 +123,13 @@ def cpu_baseline(seconds):
             "greedy_no_cache_64_tokens_s": best(lambda: t5_ref.generate_t5(sd_ng, T5_SMALL, mel1, max_length=64), 1),
         }
     stages["rtf_no_cache_64_tokens"] = stages["greedy_no_cache_64_tokens_s"] / SEG_SECONDS
+    # the same fwd + CE + bwd at 8 threads (SURVEY 8d asks for N = 8 next to the larger pool)
+    torch.set_num_threads(min(8, cores))
+    def one_step():
+        loss = t5_ref.ce_loss(t5_ref.forward_logits(sd, T5_SMALL, mel1, lab), lab)
+        loss.backward()
+    stages["fwd_bwd_8_threads_segments_per_s"] = 1.0 / best(one_step, 3)
+    torch.set_num_threads(cores)
     try:
         with open("/proc/cpuinfo") as f:
             out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
