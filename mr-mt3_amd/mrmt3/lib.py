@@ -198,32 +198,22 @@ def gemm_nt(a, b, out=None, out_dtype=None, accumulate=False):
 _ws_cache = {}
 
 
+_ws_retired = []
+
+
 def workspace(nbytes: int, device, stream=None) -> torch.Tensor:
     # one scratch buffer per (device, stream): kernels on different streams may run concurrently
     key = (device.index if hasattr(device, "index") else 0,
            (torch.cuda.current_stream() if stream is None else stream).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # kernels already queued on that stream may still be using the old buffer, and the caching allocator
+            # would hand its memory to the CURRENT stream: keep it (growth stops after the first steps)
+            _ws_retired.append(buf)
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
-
-
-def gemm_tn(a, b, out, accumulate=False, stream=None):
-    """out[N1,N2] (+)= a[M,N1]^T @ b[M,N2]  (bf16 in, f32 out).  `stream` (torch.cuda.Stream) launches there
-    instead of on the current stream, without the cost of a stream context switch."""
-    _dev(a, b, out)
-    M, N1 = a.shape
-    N2 = b.shape[1]
-    assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
-    lib = load()
-    nbytes = lib.mrmt3_gemm_tn_workspace_bytes(M, N1, N2)
-    ws = workspace(nbytes, a.device, stream)
-    sp = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
-    with _Timed("gemm_tn_bf16", 2.0 * M * N1 * N2, "FLOP", stream):
-        _check(lib.mrmt3_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N1, N2,
-                                 int(accumulate), _p(ws), ws.numel(), sp), "gemm_tn")
-    return out
 
 
 def add_rmsnorm_fwd(x0, y, w, eps, xn_dtype, write_x1=True, p=0.0, seed=0, stream_y=0, stream_out=0,
