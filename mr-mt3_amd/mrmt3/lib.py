@@ -216,6 +216,23 @@ def workspace(nbytes: int, device, stream=None) -> torch.Tensor:
     return buf
 
 
+def gemm_tn(a, b, out, accumulate=False, stream=None):
+    """out[N1,N2] (+)= a[M,N1]^T @ b[M,N2]  (bf16 in, f32 out).  `stream` (torch.cuda.Stream) launches there
+    instead of on the current stream, without the cost of a stream context switch."""
+    _dev(a, b, out)
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    lib = load()
+    nbytes = lib.mrmt3_gemm_tn_workspace_bytes(M, N1, N2)
+    ws = workspace(nbytes, a.device, stream)
+    sp = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
+    with _Timed("gemm_tn_bf16", 2.0 * M * N1 * N2, "FLOP", stream):
+        _check(lib.mrmt3_gemm_tn(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N1, N2,
+                                 int(accumulate), _p(ws), ws.numel(), sp), "gemm_tn")
+    return out
+
+
 def add_rmsnorm_fwd(x0, y, w, eps, xn_dtype, write_x1=True, p=0.0, seed=0, stream_y=0, stream_out=0,
                     out_drop=False, x1=None):
     _dev(x0, y, w)
