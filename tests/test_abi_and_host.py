@@ -76,3 +76,23 @@ def test_inference_harness_known_answers():
     ids = np.array([[0, 7, 9, 1, 5]])
     assert logmel_ref.postprocess_batch(ids).tolist() == [[4, 6, -1, -1]]
     assert prod.postprocess_batch(torch.from_numpy(ids)).tolist() == [[4, 6, -1, -1]]
+
+
+def test_every_binding_the_host_code_calls_exists():
+    """A missing Python wrapper only shows up when the GPU path runs: catch it here by scanning the host modules for
+    `lib.<name>` uses."""
+    import glob
+    import os
+    import re
+    from mrmt3 import lib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mr-mt3_amd")
+    used = set()
+    for path in glob.glob(os.path.join(root, "**", "*.py"), recursive=True) + [os.path.join(os.path.dirname(root), "bench.py"),
+                                                                                os.path.join(os.path.dirname(root), "__graft_entry__.py")]:
+        if path.endswith(os.path.join("mrmt3", "lib.py")):
+            continue
+        with open(path) as f:
+            used |= set(re.findall(r"\blib\.([A-Za-z_][A-Za-z0-9_]*)", f.read()))
+    missing = sorted(n for n in used if not hasattr(lib, n))
+    assert not missing, missing
+    assert {"gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "add_rmsnorm_bwd", "embed_bwd", "cross_entropy"} <= used
