@@ -131,6 +131,41 @@ def test_bf16_gradients_vs_oracle_autograd(dev, variant):
     assert p.grad is not None and p.grad.data_ptr() == m.flat.grad("lm_head.weight").data_ptr()
 
 
+def test_lightning_style_steps_of_the_segment_memory_tasks(dev):
+    """MT3NetSegMemV2WithPrev (3-tuple batches, cosine schedule) and its FineTune subclass (bare AdamW) driven the way
+    Lightning drives them: training_step -> backward -> optimizer step, validation_step under no_grad."""
+    from mrmt3.synthetic import T5_SMALL
+    from tasks.mt3_net_segmem_v2_with_prev import MT3NetSegMemV2WithPrev
+    from tasks.mt3_net_segmem_v2_with_prev_finetune import MT3NetSegMemV2WithPrevFineTune
+    optim_cfg = dict(lr=1e-3, warmup_steps=1, num_steps_per_epoch=10, num_epochs=1, min_lr=1e-4)
+    cfg = dict(T5_SMALL, dropout_rate=0.0, segmem_num_layers=1, segmem_length=64)
+    mel, _, lab_pad, prev = _inputs(dev)
+    lab, prv = lab_pad[:, :128].contiguous(), prev[:, :128].contiguous()
+    for cls in (MT3NetSegMemV2WithPrev, MT3NetSegMemV2WithPrevFineTune):
+        task = cls(dict(cfg), optim_cfg)
+        task.model.load_golden()
+        task.to(dev).train()
+        conf = task.configure_optimizers()
+        if isinstance(conf, tuple):
+            (opt,), (sched,) = conf
+        else:
+            opt, sched = conf, None                                 # finetune: bare AdamW (…_finetune.py:11-20)
+        assert isinstance(opt, torch.optim.AdamW)
+        losses = []
+        for it in range(5):
+            opt.zero_grad()
+            loss = task.training_step((mel, lab, prv.clone()), it)
+            loss.backward()
+            opt.step()
+            if sched is not None:
+                sched["scheduler"].step()
+            losses.append(loss.item())
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        task.eval()
+        task.validation_step((mel, lab, prv.clone()), 0)
+        assert "val_loss" in task.logged and np.isfinite(float(task.logged["val_loss"]))
+
+
 def test_grad_accumulation_and_zero_grad(dev):
     m = _build("t5", torch.bfloat16, dev)
     mel, lab_full, lab_pad, _ = _inputs(dev)
