@@ -166,6 +166,38 @@ def test_lightning_style_steps_of_the_segment_memory_tasks(dev):
         assert "val_loss" in task.logged and np.isfinite(float(task.logged["val_loss"]))
 
 
+def test_two_tuple_task_classes_step_and_weighted_loss_value(dev):
+    """MT3NetSegMem (V1), MT3NetSegMemV2 and MT3NetWeightedLoss: (inputs, targets) batches; the weighted task's loss
+    equals the oracle's weighted cross-entropy of the same logits."""
+    from mrmt3.synthetic import T5_SMALL
+    from oracle import t5_ref
+    from tasks.mt3_net import MT3NetWeightedLoss
+    from tasks.mt3_net_segmem import MT3NetSegMem
+    from tasks.mt3_net_segmem_v2 import MT3NetSegMemV2
+    optim_cfg = dict(lr=1e-3, warmup_steps=1, num_steps_per_epoch=10, num_epochs=1, min_lr=1e-4)
+    mel, _, lab_pad, _ = _inputs(dev)
+    lab = lab_pad[:, :128].contiguous()
+    for cls, extra in ((MT3NetSegMem, dict(segmem_num_layers=1, segmem_length=64)),
+                       (MT3NetSegMemV2, dict(segmem_num_layers=1, segmem_length=64)), (MT3NetWeightedLoss, {})):
+        task = cls(dict(T5_SMALL, dropout_rate=0.0, **extra), optim_cfg)
+        task.model.load_golden()
+        task.to(dev).train()
+        (opt,), _ = task.configure_optimizers()
+        opt.zero_grad()
+        loss = task.training_step((mel, lab), 0)
+        loss.backward()
+        opt.step()
+        assert np.isfinite(loss.item()) and task.model.flat.G.abs().sum().item() > 0
+        if cls is MT3NetWeightedLoss:
+            task.model.load_golden()
+            task.eval()
+            with torch.no_grad():
+                logits = task.model(inputs=mel, labels=lab)
+                got = task.training_step((mel, lab), 1).item()
+            want = t5_ref.weighted_ce_loss(logits.float().cpu(), lab.cpu()).item()
+            assert abs(got - want) < 2e-4, (got, want)
+
+
 def test_grad_accumulation_and_zero_grad(dev):
     m = _build("t5", torch.bfloat16, dev)
     mel, lab_full, lab_pad, _ = _inputs(dev)
