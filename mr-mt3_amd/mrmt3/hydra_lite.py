@@ -111,7 +111,13 @@ def _resolve(cfg, choices):
         if isinstance(node, list):
             return [walk(v) for v in node]
         if isinstance(node, str) and "${" in node:
-            return res_str(node)
+            try:
+                return res_str(node)
+            except KeyError:
+                # OmegaConf resolves lazily: an interpolation of a key this config does not define only fails when
+                # that value is read.  The reference's dataset groups are shared by top-level configs that do not all
+                # define every key they interpolate (e.g. ${split_frame_length}); leave such values unresolved.
+                return node
         return node
     return walk(cfg)
 

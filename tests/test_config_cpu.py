@@ -142,3 +142,34 @@ def test_lr_schedule_matches_reference_values():
     opt.step()
     sch.step()
     assert abs(sch.get_last_lr()[0] - 2e-4 * rec[1]["multiplier"][1]) < 1e-18
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/config"), reason="reference checkout not present")
+def test_the_reference_yaml_tree_composes_unchanged():
+    """The reference's own config directory (read in place, never copied): every top-level config composes, every
+    model group resolves `${...}` interpolations and instantiates the drop-in task class named by `_target_`, and the
+    sanity check of train.py:36 (model_type == class name) holds."""
+    import glob
+    import os
+    root = "/root/reference/config"
+    tops = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(root, "*.yaml")))
+    models = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(root, "model", "*.yaml")))
+    assert "config_slakh_segmem" in tops and "MT3NetSegMemV2WithPrev" in models
+    seen = set()
+    for top in tops:
+        cfg = hydra_lite.compose(root, top, [])
+        assert cfg.trainer.precision == 32 and int(cfg.event_length) in (256, 1024) and float(cfg.optim.lr) > 0
+        assert cfg.model_type == cfg.model._target_.split(".")[-1]
+        assert isinstance(cfg.dataset.train.root_dir, str)
+    for model in models:
+        cfg = hydra_lite.compose(root, "config_slakh_segmem", [f"model={model}"])
+        assert cfg.model_type == model
+        task = hydra_lite.instantiate(cfg.model, optim_cfg=cfg.optim, eval_cfg=cfg.eval)
+        assert type(task).__name__ == model
+        assert task.model.cfg["vocab_size"] == 1536 and task.model.cfg["d_model"] == 512
+        seen.add(type(task.model).__name__)
+        conf = task.configure_optimizers()
+        opt = conf[0][0] if isinstance(conf, tuple) else conf
+        base_lr = opt.param_groups[0].get("initial_lr", opt.param_groups[0]["lr"])     # LambdaLR starts the warm-up at 0
+        assert abs(base_lr - float(cfg.optim.lr)) < 1e-12
+    assert {"T5ForConditionalGeneration", "T5SegMem", "T5SegMemV2", "T5SegMemV2WithPrev"} <= seen
