@@ -161,6 +161,13 @@ def test_the_reference_yaml_tree_composes_unchanged():
         assert cfg.trainer.precision == 32 and int(cfg.event_length) in (256, 1024) and float(cfg.optim.lr) > 0
         assert cfg.model_type == cfg.model._target_.split(".")[-1]
         assert isinstance(cfg.dataset.train.root_dir, str)
+        # every key train.py / test.py read from the composed config
+        assert int(cfg.dataloader.train.batch_size) >= 1 and int(cfg.num_rows_per_batch) >= 1 and int(cfg.mel_length) >= 256
+        assert int(cfg.optim.warmup_steps) > 0 and int(cfg.optim.num_steps_per_epoch) > 0 and int(cfg.optim.num_epochs) > 0
+        assert float(cfg.optim.min_lr) > 0 and "path" in cfg and "seed" in cfg
+        ev = cfg.eval
+        assert "audio_dir" in ev and "eval_dataset" in ev and "exp_tag_name" in ev       # batch_size etc. are optional (test.py defaults)
+        assert isinstance(cfg.dataset.test.root_dir, str)
     for model in models:
         cfg = hydra_lite.compose(root, "config_slakh_segmem", [f"model={model}"])
         assert cfg.model_type == model
