@@ -180,3 +180,15 @@ def test_the_reference_yaml_tree_composes_unchanged():
         base_lr = opt.param_groups[0].get("initial_lr", opt.param_groups[0]["lr"])     # LambdaLR starts the warm-up at 0
         assert abs(base_lr - float(cfg.optim.lr)) < 1e-12
     assert {"T5ForConditionalGeneration", "T5SegMem", "T5SegMemV2", "T5SegMemV2WithPrev"} <= seen
+
+
+@pytest.mark.skipif(not __import__("os").path.isfile("/root/reference/pretrained/config.json"), reason="reference checkout not present")
+def test_builtin_t5_small_equals_the_reference_pretrained_config():
+    """`InferenceHandler(model=None, weight_path=...)` builds the model from mrmt3.synthetic.T5_SMALL, the reference from
+    pretrained/config.json (inference.py:36-44): the two must describe the same network."""
+    import json
+    from mrmt3.synthetic import T5_SMALL
+    with open("/root/reference/pretrained/config.json") as f:
+        ref = json.load(f)
+    assert {k: T5_SMALL[k] for k in ref} == ref
+    assert set(T5_SMALL) - set(ref) == {"use_cache"} and T5_SMALL["use_cache"] is False
