@@ -133,7 +133,14 @@ def compose(config_dir: str, config_name: str = "config", overrides=()):
                 choices[g] = opt
     plain = []
     for ov in overrides:
-        k, _, v = ov.partition("=")
+        # `key=value`; an `=` inside the value is written `\=` on the command line (e.g. a checkpoint called
+        # `...context\=0.ckpt` in the reference's test.sh)
+        k, _, v = ov.replace("\\=", "\0").partition("=")
+        k, v = k.replace("\0", "="), v.replace("\0", "=")
+        if len(v) >= 2 and v[0] == v[-1] and v[0] in "\"'":
+            v = v[1:-1]
+        if k.lstrip("+~").startswith("hydra/") or k.lstrip("+~").startswith("hydra."):
+            continue                            # Hydra's own groups (job_logging, run dir, ...): nothing to configure here
         if k.lstrip("+") in choices and "." not in k and os.path.isdir(os.path.join(config_dir, k.lstrip("+"))):
             choices[k.lstrip("+")] = v          # group selection, e.g. model=MT3NetSegMemV2WithPrev
         else:

@@ -78,7 +78,7 @@ def get_scores(model, eval_audio_dir=None, mel_norm=True, eval_dataset="Slakh", 
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config-dir", required=True)
+    ap.add_argument("--config-dir", "--config-path", dest="config_dir", required=True)   # both spellings appear in the reference's scripts
     ap.add_argument("--config-name", default="config")
     ap.add_argument("overrides", nargs="*")
     a = ap.parse_args(argv)

@@ -48,7 +48,7 @@ def synthetic_batches(cfg, rank, device, steps, with_prev):
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config-dir", required=True)
+    ap.add_argument("--config-dir", "--config-path", dest="config_dir", required=True)   # both spellings appear in the reference's scripts
     ap.add_argument("--config-name", default="config")
     ap.add_argument("overrides", nargs="*")
     a = ap.parse_args(argv)

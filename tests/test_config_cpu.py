@@ -192,3 +192,27 @@ def test_builtin_t5_small_equals_the_reference_pretrained_config():
         ref = json.load(f)
     assert {k: T5_SMALL[k] for k in ref} == ref
     assert set(T5_SMALL) - set(ref) == {"use_cache"} and T5_SMALL["use_cache"] is False
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/config"), reason="reference checkout not present")
+def test_the_reference_command_lines_compose():
+    """The override lists of the reference's train.sh / test.sh: list literals, Hydra's own `hydra/...` groups (ignored),
+    group selections, keys added with `+`, a value containing an escaped `=`, segmem_length 0."""
+    root = "/root/reference/config"
+    cfg = hydra_lite.compose(root, "config_slakh_segmem", [
+        "devices=[0,1]", "hydra/job_logging=disabled", "model=MT3NetSegMemV2WithPrev", "dataset=SlakhPrev",
+        "dataset_use_tf_spectral_ops=False", "dataset_is_randomize_tokens=True", "split_frame_length=2000",
+        "model_segmem_length=64", "trainer.check_val_every_n_epoch=20", "eval.eval_after_num_epoch=400",
+        "eval.eval_first_n_examples=3", "eval.eval_per_epoch=10", "eval.contiguous_inference=True"])
+    assert cfg.devices == [0, 1] and cfg.trainer.devices == [0, 1] and cfg.model.config.segmem_length == 64
+    assert cfg.dataset.train._target_.endswith("SlakhDatasetWithPrevSegmem") and cfg.dataset.train.split_frame_length == 2000
+    assert cfg.eval.contiguous_inference is True and cfg.dataset.train.is_randomize_tokens is True
+    cfg = hydra_lite.compose(root, "config_slakh_segmem", [
+        "model=MT3NetSegMemV2WithPrev", "path=../../../pretrained/exp_segmemV2_prev_context\\=0.ckpt", "model_segmem_length=0",
+        'eval.eval_dataset="Slakh"', "eval.exp_tag_name=slakh_mt3_official",
+        "eval.audio_dir=/data/slakh2100_flac_redux/test/*/mix_16k.wav", "eval.midi_dir=/data/slakh2100_flac_redux/test/",
+        "hydra/job_logging=disabled", "eval.is_sanity_check=True", "+eval.load_weights_strict=False"])
+    assert cfg.path.endswith("exp_segmemV2_prev_context=0.ckpt") and cfg.model.config.segmem_length == 0
+    assert cfg.eval.eval_dataset == "Slakh" and cfg.eval.load_weights_strict is False
+    with pytest.raises(KeyError):
+        hydra_lite.compose(root, "config_slakh_segmem", ["eval.no_such_key=1"])          # needs `+`, as in Hydra
