@@ -187,7 +187,7 @@ def generate(model, inputs, max_length=1024, poll_every=64):
     dec = _decoder_for(model, 1, max_length, Le + Ls)
     outs = []
     for i in range(B):
-        mem = eng.segmem(seg_ids, 1, max_length)                           # [1, Ls, d]
+        mem = _memory(eng, seg_ids, 1, max_length, Ls)                     # [1, Ls, d]
         cur = torch.cat([enc.view(B, Le, d)[i:i + 1], mem], 1).contiguous().view(Le + Ls, d)
         ckv = dec.cross_kv(cur, 1, Le + Ls)
         toks, done, fin = dec.run(ckv, 1, Le + Ls, max_length, poll_every)
@@ -198,6 +198,14 @@ def generate(model, inputs, max_length=1024, poll_every=64):
         outs.append(row)
         seg_ids = row
     return torch.cat(outs, 0)
+
+
+def _memory(eng, seg_ids, B, L, Ls):
+    """Memory vectors of the previous segment; `segmem_length=0` (the reference's no-memory ablation,
+    `[:, :0]`) yields an empty block without touching the memory encoder."""
+    if Ls == 0:
+        return torch.empty(B, 0, eng.d, device=seg_ids.device, dtype=eng.dt)
+    return eng.segmem(seg_ids, B, L)
 
 
 @torch.no_grad()
@@ -223,9 +231,10 @@ def generate_2(model, inputs, max_length=1024, poll_every=64):
         pre = dec._prefix_buf = torch.empty(1, Ls, d, device=inputs.device, dtype=torch.float32)
     outs = []
     for i in range(B):
-        pre.copy_(eng.segmem(seg_ids, 1, max_length).float().view(1, Ls, d))
+        if Ls:
+            pre.copy_(eng.segmem(seg_ids, 1, max_length).float().view(1, Ls, d))
         ckv = dec.cross_kv(enc.view(B, Le, d)[i].contiguous(), 1, Le)
-        toks, done, fin = dec.run(ckv, 1, Le, max_length, poll_every, prefix=pre)
+        toks, done, fin = dec.run(ckv, 1, Le, max_length, poll_every, prefix=pre if Ls else None)
         steps = (fin + 1) if fin >= 0 else max_length
         row = torch.zeros(1, max_length, dtype=torch.int64, device=inputs.device)
         n = min(steps + 1, max_length)
@@ -274,7 +283,7 @@ def generate_songs(model, songs, max_length=1024, poll_every=64):
         live = [s for s in range(S) if i < songs[s].shape[0]]
         B = len(live)
         seg_ids = torch.stack([prev[s] for s in live])                      # [B, max_length]
-        mem = eng.segmem(seg_ids, B, max_length)                           # [B, Ls, d]
+        mem = _memory(eng, seg_ids, B, max_length, Ls)                     # [B, Ls, d]
         cur = torch.cat([torch.stack([enc[s][i] for s in live]), mem.to(enc[0].dtype)], 1).contiguous()
         dec = _decoder_for(model, B, max_length, Le + Ls)
         ckv = dec.cross_kv(cur.view(B * (Le + Ls), d), B, Le + Ls)

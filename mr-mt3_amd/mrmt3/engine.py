@@ -389,10 +389,15 @@ class Engine:
         pos = self.pos(mel.device)
         variant = self.variant
         mem = None
+        if variant == "segmem_v2_with_prev":
+            assert targets_prev is not None
+            targets_prev.masked_fill_(targets_prev == -100, pad)                 # in place, like the reference (:119)
+        if Ls == 0:
+            # model_segmem_length=0 (the reference's no-memory ablation): `[:, :0]` leaves nothing to attend
+            # to or prepend, so the step is the plain MT3 one and the memory block receives no gradient
+            variant = "t5"
         if variant != "t5":
             if variant == "segmem_v2_with_prev":
-                assert targets_prev is not None
-                targets_prev.masked_fill_(targets_prev == -100, pad)             # in place, like the reference (:119)
                 ids = targets_prev.contiguous()
             else:
                 ids = self.prev_row_ids(labels, start, pad)
@@ -418,7 +423,7 @@ class Engine:
                 enc_cat, Lc = enc, Le
         if tape is not None:
             tape.push(kind="dec_in", s_emb=s_emb, p=p, labels=labels, B=B, Le=Le, Ld=Ld, Lx=Lx, Lc=Lc, Ls=Ls,
-                      Lm=(ids.shape[1] if variant != "t5" else 0))
+                      Lm=(ids.shape[1] if variant != "t5" else 0), variant=variant)
         dec = self.stack_fwd("decoder", x, B, Lx, cfg["num_decoder_layers"], True, enc=enc_cat, Le=Lc, p=p, tape=tape)
         if variant == "segmem_v1":
             dec = dec.view(B, Lx, d)[:, Ls:].contiguous().view(B * Ld, d)
@@ -443,6 +448,7 @@ class Engine:
         # peek the decoder-input record (it sits below the decoder stack's records)
         din = next(o for o in reversed(tape.ops) if o["kind"] == "dec_in")
         B, Le, Ld, Lx, Lc, Ls = din["B"], din["Le"], din["Ld"], din["Lx"], din["Lc"], din["Ls"]
+        variant = din["variant"]                                # "t5" when segmem_length is 0
         if variant == "segmem_v1":
             full = torch.zeros(B, Lx, d, device=d_dec.device, dtype=torch.float32)
             full[:, Ls:] = d_dec.view(B, Ld, d)

@@ -433,3 +433,33 @@ def test_lockstep_decode_of_several_recordings_equals_one_at_a_time(dev, variant
         alone = m.generate(mel, max_length=80)
         assert torch.equal(together[s], alone), s
     assert any((t == 1).any().item() for t in together), "EOS never fired; raise the boost"
+
+
+def test_segment_memory_length_zero_is_plain_mt3(dev):
+    """test.sh's `model_segmem_length=0` experiment ("MR-MT3 with no memory block, which is basically MT3"): with an
+    empty memory the V2WithPrev model's logits and greedy tokens equal the plain T5's on the same weights."""
+    from mrmt3.synthetic import T5_SMALL, golden_weights
+    from models.t5 import T5ForConditionalGeneration
+    from models.t5_segmem_v2_with_prev import T5SegMemV2WithPrev
+    w = golden_weights(T5_SMALL, 1)
+    m0 = T5SegMemV2WithPrev(T5_SMALL, segmem_num_layers=1, segmem_length=0, compute_dtype=torch.float32).to(dev).eval()
+    t5 = T5ForConditionalGeneration(T5_SMALL, compute_dtype=torch.float32).to(dev).eval()
+    with torch.no_grad():
+        m0.flat.load_numpy(w)
+        t5.flat.load_numpy({k: v for k, v in w.items() if not k.startswith("segmem")})
+    mel, _, lab_pad, prev = _inputs(dev)
+    with torch.no_grad():
+        a = m0(inputs=mel, labels=lab_pad, targets_prev=prev.clone())
+        b = t5(inputs=mel, labels=lab_pad)
+    assert torch.allclose(a, b, atol=1e-5)
+    ids0 = m0.generate(mel, max_length=48)
+    for i in range(mel.shape[0]):                               # the segmem model decodes segment by segment, padded to max_length
+        ref = t5.generate(mel[i:i + 1], max_length=48)[0]
+        n = min(48, ref.numel())
+        assert torch.equal(ids0[i, :n], ref[:n])
+    # and the bf16 training step runs with an empty memory
+    mb = T5SegMemV2WithPrev(T5_SMALL, segmem_num_layers=1, segmem_length=0).load_golden().to(dev)
+    mb.train()
+    out = mb(inputs=mel, labels=lab_pad[:, :128].contiguous(), targets_prev=prev[:, :128].clone())
+    out.float().mean().backward()
+    assert torch.isfinite(mb.flat.G).all()
