@@ -70,6 +70,16 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 __device__ __forceinline__ float keep_of(const AttnDrop& d, unsigned h, unsigned shift) {
   return ((h >> shift) & 0xFFu) >= d.thresh8 ? d.scale : 0.f;
 }
+// max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): gfx950's v_permlane16/32_swap are
+// plain VALU moves, so the reduction has no LDS (ds_bpermute) round trip in the softmax's dependency chain
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows_max(float v) {
+  unsigned u = __float_as_uint(v);
+  u32x2_t r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(r.x), __uint_as_float(r.y)));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -103,6 +113,21 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* tile, int row, in
   const unsigned char* a = tile + row * 128 + ((c ^ (row & 7)) << 4) + sub;
   return cat8(lds_tr16(a), lds_tr16(a + 16 * 128));
 }
+
+// Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8) and each XCD has its own L2.  All tiles
+// of one (batch, head) stream the same K/V (or Q/dO) rows, so they are made to run on ONE XCD, back to back:
+// XCD x takes the contiguous range [x*n/8, (x+1)*n/8) of the (b, h, tile) space, tile fastest.  Without this the
+// 8 query tiles of a head land on 8 different XCDs and every one of them pulls K/V through the fabric again.
+__device__ __forceinline__ void attn_tile(int& tile, int& h, int& b) {
+  const int nt = gridDim.x, H = gridDim.y;
+  const int n = nt * H * (int)gridDim.z;
+  int w = blockIdx.x + nt * (blockIdx.y + H * blockIdx.z);
+  if ((n & 7) == 0) w = (w & 7) * (n >> 3) + (w >> 3);
+  tile = w % nt;
+  const int bh = w / nt;
+  h = bh % H;
+  b = bh / H;
+}
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // ------------------------------------------------------------------------------------------------
@@ -117,7 +142,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   // causal: later query tiles see more keys; dispatch the heaviest first so the launch does not end on them
-  const int q0 = (P.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, h = blockIdx.y, b = blockIdx.z;
+  int tile_, h, b;
+  attn_tile(tile_, h, b);
+  const int q0 = (P.causal ? (int)gridDim.x - 1 - tile_ : tile_) * 128;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
@@ -202,8 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sT[qt][kt][r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      mloc = rows_max(mloc);
       // running max kept in the exp2 domain (m2 = max * log2 e): p = exp2(s*log2e - m2)
       const float m_new = fmaxf(m_run[qt], mloc * LOG2E);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -280,7 +306,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
-  const int k0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+  int tile_, h, b;
+  attn_tile(tile_, h, b);
+  const int k0 = tile_ * 128;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
@@ -426,7 +454,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   // causal: later query tiles see more keys; dispatch the heaviest first so the launch does not end on them
-  const int q0 = (P.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128, h = blockIdx.y, b = blockIdx.z;
+  int tile_, h, b;
+  attn_tile(tile_, h, b);
+  const int q0 = (P.causal ? (int)gridDim.x - 1 - tile_ : tile_) * 128;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
