@@ -128,26 +128,47 @@ __device__ __forceinline__ void attn_tile(int& tile, int& h, int& b) {
   h = bh % H;
   b = bh / H;
 }
+// causal launches pair the 128-row tiles (see the kernels): ceil(n/2) workgroups along x
+static inline int attn_grid_x(int L, int causal) {
+  const int n = ceil_div(L, 128);
+  return causal ? (n + 1) / 2 : n;
+}
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 #define KV_STAGES 3
+#ifndef FWD_PAIR_OCC
+#define FWD_PAIR_OCC 3
+#endif
 #define KV_STAGE_BYTES 16384   // K tile 8 KiB + V tile 8 KiB
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
+template <bool PAIR>
+__global__ __launch_bounds__(256, PAIR ? FWD_PAIR_OCC : 2) void attn_fwd_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
-  // causal: later query tiles see more keys; dispatch the heaviest first so the launch does not end on them
   int tile_, h, b;
   attn_tile(tile_, h, b);
-  const int q0 = (P.causal ? (int)gridDim.x - 1 - tile_ : tile_) * 128;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
+  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  const int n_qt = ceil_div(P.Lq, 128);
+
+  // causal: query tile t needs 2(t+1) key tiles, so a workgroup takes the PAIR (n_qt-1-t, t) — every workgroup
+  // of the launch then does the same amount of work and the launch has no tail of heavy tiles
+#pragma nounroll
+  for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+  int q_tile = tile_;
+  if (PAIR) {
+    q_tile = pass == 0 ? n_qt - 1 - tile_ : tile_;
+    if (pass == 1 && 2 * tile_ == n_qt - 1) break;
+    if (pass == 1) __syncthreads();      // every wave is done reading the previous tile's LDS stages
+  }
+  const int q0 = q_tile * 128;
 
   // Q fragments (B operand): lane holds Q[q = qrow(qt)][d = 32ks + 8g .. +7]
   bf16x8 qf[2][2];
@@ -183,7 +204,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
   };
   stage(0, 0);
   if (n_kv > 1) stage(1, 64);
-  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
   int cur = 0;
 
   for (int j = 0; j < n_kv; ++j) {
@@ -292,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     }
     if (fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] * LN2 + __logf(l);
   }
+  }  // pass
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 #define QD_STAGES 4
 #define QD_STAGE_BYTES 8448   // Q 4 KiB + dO 4 KiB + 64 floats
 
+template <bool PAIR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[QD_STAGES * QD_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -308,13 +330,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   int tile_, h, b;
   attn_tile(tile_, h, b);
-  const int k0 = tile_ * 128;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
   const float* lse = P.lse + ((size_t)b * P.H + h) * P.Lq;
   const float* dlt = P.delta + ((size_t)b * P.H + h) * P.Lq;
+  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  const int n_kt = ceil_div(P.Lk, 128);
+
+  // causal: key tile t is seen by the queries from 128 t on, so the pair (t, n_kt-1-t) balances the launch
+#pragma nounroll
+  for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+  int k_tile = tile_;
+  if (PAIR) {
+    k_tile = pass == 0 ? tile_ : n_kt - 1 - tile_;
+    if (pass == 1 && 2 * tile_ == n_kt - 1) break;
+    if (pass == 1) __syncthreads();
+  }
+  const int k0 = k_tile * 128;
 
   bf16x8 kf[2][2], vf[2][2];
   int key[2];
@@ -347,7 +381,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
                                      (__attribute__((address_space(3))) void*)(base + 8192), 4, 0, 0);
   };
   for (int i = 0; i < 3 && i < nblk; ++i) stage(i, qstart + i * 32);
-  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
   int cur = 0;
 
   for (int it = 0; it < nblk; ++it) {
@@ -443,24 +476,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
       *(u32x2*)(dvrow + dt * 16 + fg * 4) = u32x2{pack_bf2(c[0], c[1]), pack_bf2(c[2], c[3])};
     }
   }
+  }  // pass
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward: dQ.  workgroup = 128 queries (wave = 32, query on the lane), loop over 64-key tiles
 // ------------------------------------------------------------------------------------------------
+template <bool PAIR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
-  // causal: later query tiles see more keys; dispatch the heaviest first so the launch does not end on them
   int tile_, h, b;
   attn_tile(tile_, h, b);
-  const int q0 = (P.causal ? (int)gridDim.x - 1 - tile_ : tile_) * 128;
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
+  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  const int n_qt = ceil_div(P.Lq, 128);
+
+  // causal: the pair of query tiles (n_qt-1-t, t), as in the forward kernel
+#pragma nounroll
+  for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+  int q_tile = tile_;
+  if (PAIR) {
+    q_tile = pass == 0 ? n_qt - 1 - tile_ : tile_;
+    if (pass == 1 && 2 * tile_ == n_qt - 1) break;
+    if (pass == 1) __syncthreads();
+  }
+  const int q0 = q_tile * 128;
 
   bf16x8 qf[2][2], dof[2][2];
   int qrow[2];
@@ -509,7 +555,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
   };
   stage(0, 0);
   if (n_kv > 1) stage(1, 64);
-  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
   int cur = 0;
 
   for (int j = 0; j < n_kv; ++j) {
@@ -586,6 +631,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
       *(u32x2*)(row + dt * 16 + fg * 4) = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
     }
   }
+  }  // pass
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,7 +715,8 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(256), 0, s, P);
+  if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(attn_grid_x(Lq, 1), H, B), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(attn_grid_x(Lq, 0), H, B), dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_fwd");
   return MRMT3_OK;
 }
@@ -692,9 +739,11 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   P.drop = make_attn_drop(p_drop, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
   // dQ first: it derives delta = rowsum(dO * O) from operands it loads anyway and leaves it for dK/dV
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(Lq, 128), H, B), dim3(256), 0, s, P);
+  if (causal) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(attn_grid_x(Lq, 1), H, B), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(attn_grid_x(Lq, 0), H, B), dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dq");
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(ceil_div(Lk, 128), H, B), dim3(256), 0, s, P);
+  if (causal) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(attn_grid_x(Lk, 1), H, B), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(attn_grid_x(Lk, 0), H, B), dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dkdv");
   return MRMT3_OK;
 }
