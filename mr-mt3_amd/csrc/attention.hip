@@ -43,7 +43,9 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
 // the element.  Every kernel layout (4 consecutive keys per lane in forward/dQ, 4 consecutive
 // queries per lane in dK/dV) therefore needs 2 mixes per 4 elements.  The drop probability is
 // quantised to thresh8/256 (p=0.1 -> 26/256) and the keep scale is 256/(256-thresh8), so forward
-// and backward stay exactly consistent and unbiased.
+// and backward stay exactly consistent and unbiased.  The kernels only ZERO the dropped probabilities
+// in the loop; the constant keep scale is applied once to the accumulated O / dV (and inside the
+// fused multiply-add that forms dS), which takes a multiply per element out of the inner loop.
 struct AttnDrop {
   unsigned seed;
   unsigned thresh8;  // 0 = off
@@ -63,12 +65,17 @@ __host__ inline AttnDrop make_attn_drop(float p, unsigned long long seed, unsign
   }
   return d;
 }
-__device__ __forceinline__ unsigned mix32(unsigned x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+// VALU and MFMA do not overlap on a gfx950 SIMD (profiles/tools/coissue_probe.hip), so every instruction of
+// the mask costs kernel time.  32-bit integer multiplies are quarter rate; v_mul_u32_u24 is full rate, and
+// with the xor-shifts folding the high bits down first the two 24-bit multiplies mix just as well here
+// (byte histograms, keep rate and neighbour correlations checked against the 32-bit finaliser).
+__device__ __forceinline__ unsigned mix24(unsigned x) {
+  x ^= x >> 16; x = __umul24(x, 0x7feb35u); x ^= x >> 15; x = __umul24(x, 0x6ca68bu); x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float keep_of(const AttnDrop& d, unsigned h, unsigned shift) {
-  return ((h >> shift) & 0xFFu) >= d.thresh8 ? d.scale : 0.f;
+// `g` is the group's mix already shifted so that this lane's two elements sit in bytes `byte` (0..3, constant)
+__device__ __forceinline__ float drop_sel(const AttnDrop& d, unsigned g, int byte, float v) {
+  return ((g >> (8 * byte)) & 0xFFu) >= d.thresh8 ? v : 0.f;
 }
 // max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): gfx950's v_permlane16/32_swap are
 // plain VALU moves, so the reduction has no LDS (ds_bpermute) round trip in the softmax's dependency chain
@@ -139,13 +146,10 @@ static inline int attn_grid_x(int L, int causal) {
 // forward
 // ------------------------------------------------------------------------------------------------
 #define KV_STAGES 3
-#ifndef FWD_PAIR_OCC
-#define FWD_PAIR_OCC 3
-#endif
 #define KV_STAGE_BYTES 16384   // K tile 8 KiB + V tile 8 KiB
 
 template <bool PAIR>
-__global__ __launch_bounds__(256, PAIR ? FWD_PAIR_OCC : 2) void attn_fwd_kernel(AttnParams P) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
@@ -250,11 +254,20 @@ __global__ __launch_bounds__(256, PAIR ? FWD_PAIR_OCC : 2) void attn_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sT[qt][kt][r]);
       mloc = rows_max(mloc);
-      // running max kept in the exp2 domain (m2 = max * log2 e): p = exp2(s*log2e - m2)
-      const float m_new = fmaxf(m_run[qt], mloc * LOG2E);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
-      m_run[qt] = m_new;
+      // running max kept in the exp2 domain (m2 = max * log2 e): p = exp2(s*log2e - m2).  The reference point
+      // only has to keep exp2 in range, not to BE the max: it is moved (and O, l rescaled) only when some row of
+      // the wave outgrew it by more than 2^8, so most tiles skip the rescale altogether (p <= 256 then).
+      const float m_cand = fmaxf(m_run[qt], mloc * LOG2E);
+      const bool grow = m_cand > m_run[qt] + 8.f;
+      if (__builtin_amdgcn_ballot_w64(grow)) {
+        const float m_new = grow ? m_cand : m_run[qt];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - ((m_new == -INFINITY) ? 0.f : m_new));
+        m_run[qt] = m_new;
+        l_run[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oT[qt][dt] *= alpha;
+      }
+      const float m_use = (m_run[qt] == -INFINITY) ? 0.f : m_run[qt];
       float lsum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -264,20 +277,18 @@ __global__ __launch_bounds__(256, PAIR ? FWD_PAIR_OCC : 2) void attn_fwd_kernel(
           lsum += p;
           sT[qt][kt][r] = p;
         }
-      l_run[qt] = l_run[qt] * alpha + lsum;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) oT[qt][dt] *= alpha;
+      l_run[qt] += lsum;
       if (P.drop.thresh8) {
         const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
         const unsigned sh = (qrow[qt] & 1) << 4;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
           const unsigned kp = (unsigned)(kv0 + kt * 16 + fg * 4) >> 1;
-          const unsigned h0 = mix32(qb_ + kp * DROP_CK), h1 = mix32(qb_ + (kp + 1) * DROP_CK);
-          sT[qt][kt][0] *= keep_of(P.drop, h0, sh);
-          sT[qt][kt][1] *= keep_of(P.drop, h0, sh + 8);
-          sT[qt][kt][2] *= keep_of(P.drop, h1, sh);
-          sT[qt][kt][3] *= keep_of(P.drop, h1, sh + 8);
+          const unsigned g0 = mix24(qb_ + kp * DROP_CK) >> sh, g1 = mix24(qb_ + (kp + 1) * DROP_CK) >> sh;
+          sT[qt][kt][0] = drop_sel(P.drop, g0, 0, sT[qt][kt][0]);
+          sT[qt][kt][1] = drop_sel(P.drop, g0, 1, sT[qt][kt][1]);
+          sT[qt][kt][2] = drop_sel(P.drop, g1, 0, sT[qt][kt][2]);
+          sT[qt][kt][3] = drop_sel(P.drop, g1, 1, sT[qt][kt][3]);
         }
       }
     }
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(256, PAIR ? FWD_PAIR_OCC : 2) void attn_fwd_kernel(
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (qrow[qt] >= P.Lq) continue;
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const float inv = l > 0.f ? P.drop.scale / l : 0.f;    // the dropout keep scale is applied here, once
     bf16_t* orow = P.out + ((size_t)b * P.Lq + qrow[qt]) * P.ldo + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -429,21 +440,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
             if (!valid) pv[r] = 0.f;
           }
         }
-        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        float pk[4] = {pv[0], pv[1], pv[2], pv[3]}, dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
         if (P.drop.thresh8) {
           const unsigned qp = (unsigned)(qb0 + qt * 16 + fg * 4) >> 1;
           const unsigned kb_ = drop_bh + ((unsigned)key[nt] >> 1) * DROP_CK;
-          const unsigned h0 = mix32(kb_ + qp * DROP_CQ), h1 = mix32(kb_ + (qp + 1) * DROP_CQ);
           const unsigned sh = (key[nt] & 1) << 3;
-          kp[0] = keep_of(P.drop, h0, sh);
-          kp[1] = keep_of(P.drop, h0, sh + 16);
-          kp[2] = keep_of(P.drop, h1, sh);
-          kp[3] = keep_of(P.drop, h1, sh + 16);
+          const unsigned g0 = mix24(kb_ + qp * DROP_CQ) >> sh, g1 = mix24(kb_ + (qp + 1) * DROP_CQ) >> sh;
+          pk[0] = drop_sel(P.drop, g0, 0, pk[0]); dk_[0] = drop_sel(P.drop, g0, 0, dk_[0]);
+          pk[1] = drop_sel(P.drop, g0, 2, pk[1]); dk_[1] = drop_sel(P.drop, g0, 2, dk_[1]);
+          pk[2] = drop_sel(P.drop, g1, 0, pk[2]); dk_[2] = drop_sel(P.drop, g1, 0, dk_[2]);
+          pk[3] = drop_sel(P.drop, g1, 2, pk[3]); dk_[3] = drop_sel(P.drop, g1, 2, dk_[3]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pd[qt][nt][r] = pv[r] * kp[r];
-          ds[qt][nt][r] = pv[r] * (dp[r] * kp[r] - drow[r]);
+          pd[qt][nt][r] = pk[r];                                           // keep scale: applied to dV at the end
+          ds[qt][nt][r] = pv[r] * fmaf(dk_[r], P.drop.scale, -drow[r]);
         }
       }
     }
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
     bf16_t* dvrow = P.dv + ((size_t)b * P.Lk + key[nt]) * P.lddv + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      f32x4 a = dkT[nt][dt], c = dvT[nt][dt];
+      f32x4 a = dkT[nt][dt], c = dvT[nt][dt] * P.drop.scale;
       *(u32x2*)(dkrow + dt * 16 + fg * 4) = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
       *(u32x2*)(dvrow + dt * 16 + fg * 4) = u32x2{pack_bf2(c[0], c[1]), pack_bf2(c[2], c[3])};
     }
@@ -592,19 +603,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
             if (key >= P.Lk || (P.causal && key > qrow[qt])) pv[r] = 0.f;
           }
         }
-        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        float dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
         if (P.drop.thresh8) {
           const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
           const unsigned sh = (qrow[qt] & 1) << 4;
           const unsigned kpi = (unsigned)(kv0 + kt * 16 + fg * 4) >> 1;
-          const unsigned h0 = mix32(qb_ + kpi * DROP_CK), h1 = mix32(qb_ + (kpi + 1) * DROP_CK);
-          kp[0] = keep_of(P.drop, h0, sh);
-          kp[1] = keep_of(P.drop, h0, sh + 8);
-          kp[2] = keep_of(P.drop, h1, sh);
-          kp[3] = keep_of(P.drop, h1, sh + 8);
+          const unsigned g0 = mix24(qb_ + kpi * DROP_CK) >> sh, g1 = mix24(qb_ + (kpi + 1) * DROP_CK) >> sh;
+          dk_[0] = drop_sel(P.drop, g0, 0, dk_[0]);
+          dk_[1] = drop_sel(P.drop, g0, 1, dk_[1]);
+          dk_[2] = drop_sel(P.drop, g1, 0, dk_[2]);
+          dk_[3] = drop_sel(P.drop, g1, 1, dk_[3]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dsT[qt][kt][r] = pv[r] * (dp[r] * kp[r] - dlt_q[qt]);
+        for (int r = 0; r < 4; ++r) dsT[qt][kt][r] = pv[r] * fmaf(dk_[r], P.drop.scale, -dlt_q[qt]);
       }
     }
 #pragma unroll
