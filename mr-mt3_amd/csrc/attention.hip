@@ -140,6 +140,20 @@ static inline int attn_grid_x(int L, int causal) {
   const int n = ceil_div(L, 128);
   return causal ? (n + 1) / 2 : n;
 }
+// K/V (Q/dO) tiles are staged with buffer_load ... lds: the per-lane byte offset inside an 8-row group is constant
+// for the whole kernel, the tile offset is a scalar, and rows past the end of the tensor (or a whole tile that is
+// switched off by an out-of-range scalar offset) come back as zeros without touching memory — so the loop needs no
+// address arithmetic, no row clamp and no branch around the prefetch.
+#define BUF_OOB 0x7FFF0000
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const bf16_t* base, int nrows, int ld) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, ((nrows - 1) * ld + HD) * 2, 0x00020000);
+}
+__device__ __forceinline__ unsigned rows8_lane_off(int ld, int lane) {     // row lane>>3, swizzled 16-B chunk
+  return (unsigned)(((lane >> 3) * ld + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+}
+__device__ __forceinline__ void blds_rows8(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int tile_byte_off, unsigned char* dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, lane_off, tile_byte_off, 0, 0);
+}
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // ------------------------------------------------------------------------------------------------
@@ -148,7 +162,7 @@ static inline int attn_grid_x(int L, int causal) {
 #define KV_STAGES 3
 #define KV_STAGE_BYTES 16384   // K tile 8 KiB + V tile 8 KiB
 
-template <bool PAIR>
+template <bool PAIR, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,6 +175,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
   const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
   const int n_qt = ceil_div(P.Lq, 128);
+  const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk), vres = rows_rsrc(vb, P.Lk, P.ldv);
+  const unsigned k_lane = rows8_lane_off(P.ldk, lane), v_lane = rows8_lane_off(P.ldv, lane);
 
   // causal: query tile t needs 2(t+1) key tiles, so a workgroup takes the PAIR (n_qt-1-t, t) — every workgroup
   // of the launch then does the same amount of work and the launch has no tail of heavy tiles
@@ -196,25 +212,26 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
 
   int n_kv = ceil_div(P.Lk, 64);
   if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
-  // each wave stages 16 rows of K and of V per tile (2 + 2 wave-instructions)
-  auto stage = [&](int buf, int kv0) {
+  // each wave stages 16 rows of K and of V per tile (2 + 2 wave-instructions); `on` = false turns the tile into
+  // four zero-fills that never leave the CU, which keeps the vmcnt arithmetic of the loop uniform
+  auto stage = [&](int buf, int kv0, bool on) {
     unsigned char* base = lds + buf * KV_STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int t = uw * 2 + i;
-      glds_rows8(kb, P.ldk, kv0 + t * 8, P.Lk, base + t * 1024, lane);
-      glds_rows8(vb, P.ldv, kv0 + t * 8, P.Lk, base + 8192 + t * 1024, lane);
+      blds_rows8(kres, k_lane, on ? (kv0 + t * 8) * P.ldk * 2 : BUF_OOB, base + t * 1024);
+      blds_rows8(vres, v_lane, on ? (kv0 + t * 8) * P.ldv * 2 : BUF_OOB, base + 8192 + t * 1024);
     }
   };
-  stage(0, 0);
-  if (n_kv > 1) stage(1, 64);
+  stage(0, 0, true);
+  stage(1, 64, n_kv > 1);
   int cur = 0;
 
   for (int j = 0; j < n_kv; ++j) {
     const int kv0 = j * 64;
-    if (j + 1 < n_kv) VMCNT(4); else VMCNT(0);      // tile j landed (tile j+1 may still be in flight)
+    VMCNT(4);                                       // tile j landed (tile j+1 may still be in flight)
     __builtin_amdgcn_s_barrier();
-    if (j + 2 < n_kv) stage(cur == 0 ? 2 : cur - 1, kv0 + 128);
+    stage(cur == 0 ? 2 : cur - 1, kv0 + 128, j + 2 < n_kv);
     const unsigned char* lk = lds + cur * KV_STAGE_BYTES;
     const unsigned char* lv = lk + 8192;
     cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * 32);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      if (need_mask) {
+      if (__builtin_expect(need_mask, 0)) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
       // the wave outgrew it by more than 2^8, so most tiles skip the rescale altogether (p <= 256 then).
       const float m_cand = fmaxf(m_run[qt], mloc * LOG2E);
       const bool grow = m_cand > m_run[qt] + 8.f;
-      if (__builtin_amdgcn_ballot_w64(grow)) {
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(grow) != 0, 0)) {
         const float m_new = grow ? m_cand : m_run[qt];
         const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - ((m_new == -INFINITY) ? 0.f : m_new));
         m_run[qt] = m_new;
@@ -278,7 +295,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
           sT[qt][kt][r] = p;
         }
       l_run[qt] += lsum;
-      if (P.drop.thresh8) {
+      // DROP only removes the block for p = 0.  With dropout on, the test stays a run-time one on purpose: as its own
+      // basic block the mask code keeps its registers to itself (164 VGPRs, no spill); merged into the exp loop by the
+      // scheduler the kernel spills and is 12% slower.
+      if (DROP && P.drop.thresh8) {
         const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
         const unsigned sh = (qrow[qt] & 1) << 4;
 #pragma unroll
@@ -307,6 +327,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     }
     }  // wave_active
   }
+  VMCNT(0);      // the switched-off prefetches of the last two iterations still write their zeros
 
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
 #define QD_STAGES 4
 #define QD_STAGE_BYTES 8448   // Q 4 KiB + dO 4 KiB + 64 floats
 
-template <bool PAIR>
+template <bool PAIR, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[QD_STAGES * QD_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -349,6 +370,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   const float* dlt = P.delta + ((size_t)b * P.H + h) * P.Lq;
   const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
   const int n_kt = ceil_div(P.Lk, 128);
+  const __amdgpu_buffer_rsrc_t qres = rows_rsrc(qb, P.Lq, P.ldq), dores = rows_rsrc(dob, P.Lq, P.lddo);
+  const unsigned q_lane = rows8_lane_off(P.ldq, lane), do_lane = rows8_lane_off(P.lddo, lane);
 
   // causal: key tile t is seen by the queries from 128 t on, so the pair (t, n_kt-1-t) balances the launch
 #pragma nounroll
@@ -381,25 +404,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
 
   const int qstart = P.causal ? (k0 / 32) * 32 : 0;
   const int nblk = qstart < P.Lq ? ceil_div(P.Lq - qstart, 32) : 0;
-  // per tile every wave issues: 8 rows of Q, 8 rows of dO, and the 64 row statistics (the same
-  // 256 bytes from all four waves — identical data, keeps the vmcnt arithmetic uniform)
-  auto stage = [&](int buf, int qb0) {
+  // per tile every wave issues: 8 rows of Q, 8 rows of dO, and the 64 row statistics (the same 256 bytes from all
+  // four waves — identical data, keeps the vmcnt arithmetic uniform).  `on` = false: zero-fills that stay on the CU
+  // (the statistics are simply read again), so the loop below prefetches and waits without a branch.
+  auto stage = [&](int buf, int qb0, bool on) {
     unsigned char* base = lds + buf * QD_STAGE_BYTES;
-    glds_rows8(qb, P.ldq, qb0 + uw * 8, P.Lq, base + uw * 1024, lane);
-    glds_rows8(dob, P.lddo, qb0 + uw * 8, P.Lq, base + 4096 + uw * 1024, lane);
+    blds_rows8(qres, q_lane, on ? (qb0 + uw * 8) * P.ldq * 2 : BUF_OOB, base + uw * 1024);
+    blds_rows8(dores, do_lane, on ? (qb0 + uw * 8) * P.lddo * 2 : BUF_OOB, base + 4096 + uw * 1024);
     const float* sp = (lane < 32 ? lse : dlt) + min(qb0 + (lane & 31), P.Lq - 1);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
                                      (__attribute__((address_space(3))) void*)(base + 8192), 4, 0, 0);
   };
-  for (int i = 0; i < 3 && i < nblk; ++i) stage(i, qstart + i * 32);
+  for (int i = 0; i < 3; ++i) stage(i, qstart + i * 32, i < nblk);
   int cur = 0;
 
   for (int it = 0; it < nblk; ++it) {
     const int qb0 = qstart + it * 32;
-    const int ahead = min(2, nblk - 1 - it);   // tiles that may stay in flight (3 loads each)
-    if (ahead == 2) VMCNT(6); else if (ahead == 1) VMCNT(3); else VMCNT(0);
+    VMCNT(6);                                  // two younger tiles (3 loads each) may stay in flight
     __builtin_amdgcn_s_barrier();
-    if (it + 3 < nblk) stage(cur == 0 ? 3 : cur - 1, qb0 + 96);
+    stage(cur == 0 ? 3 : cur - 1, qb0 + 96, it + 3 < nblk);
     const unsigned char* lq = lds + cur * QD_STAGE_BYTES;
     const unsigned char* ldo_ = lq + 4096;
     const float* lstat = (const float*)(lq + 8192);   // [0..31] lse, [32..63] delta
@@ -432,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
         float pv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lrow[r]));
-        if (need_mask) {
+        if (__builtin_expect(need_mask, 0)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = qb0 + qt * 16 + fg * 4 + r;
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
           }
         }
         float pk[4] = {pv[0], pv[1], pv[2], pv[3]}, dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
-        if (P.drop.thresh8) {
+        if (DROP && P.drop.thresh8) {    // run-time test on purpose, see the forward kernel
           const unsigned qp = (unsigned)(qb0 + qt * 16 + fg * 4) >> 1;
           const unsigned kb_ = drop_bh + ((unsigned)key[nt] >> 1) * DROP_CK;
           const unsigned sh = (key[nt] & 1) << 3;
@@ -475,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
     }
     }  // wave_active
   }
+  VMCNT(0);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     if (key[nt] >= P.Lk) continue;
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
 // ------------------------------------------------------------------------------------------------
 // backward: dQ.  workgroup = 128 queries (wave = 32, query on the lane), loop over 64-key tiles
 // ------------------------------------------------------------------------------------------------
-template <bool PAIR>
+template <bool PAIR, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -507,6 +531,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
   const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
   const int n_qt = ceil_div(P.Lq, 128);
+  const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk), vres = rows_rsrc(vb, P.Lk, P.ldv);
+  const unsigned k_lane = rows8_lane_off(P.ldk, lane), v_lane = rows8_lane_off(P.ldv, lane);
 
   // causal: the pair of query tiles (n_qt-1-t, t), as in the forward kernel
 #pragma nounroll
@@ -555,24 +581,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
 
   int n_kv = ceil_div(P.Lk, 64);
   if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
-  auto stage = [&](int buf, int kv0) {
+  auto stage = [&](int buf, int kv0, bool on) {      // as in the forward kernel
     unsigned char* base = lds + buf * KV_STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int t = uw * 2 + i;
-      glds_rows8(kb, P.ldk, kv0 + t * 8, P.Lk, base + t * 1024, lane);
-      glds_rows8(vb, P.ldv, kv0 + t * 8, P.Lk, base + 8192 + t * 1024, lane);
+      blds_rows8(kres, k_lane, on ? (kv0 + t * 8) * P.ldk * 2 : BUF_OOB, base + t * 1024);
+      blds_rows8(vres, v_lane, on ? (kv0 + t * 8) * P.ldv * 2 : BUF_OOB, base + 8192 + t * 1024);
     }
   };
-  stage(0, 0);
-  if (n_kv > 1) stage(1, 64);
+  stage(0, 0, true);
+  stage(1, 64, n_kv > 1);
   int cur = 0;
 
   for (int j = 0; j < n_kv; ++j) {
     const int kv0 = j * 64;
-    if (j + 1 < n_kv) VMCNT(4); else VMCNT(0);
+    VMCNT(4);
     __builtin_amdgcn_s_barrier();
-    if (j + 2 < n_kv) stage(cur == 0 ? 2 : cur - 1, kv0 + 128);
+    stage(cur == 0 ? 2 : cur - 1, kv0 + 128, j + 2 < n_kv);
     const unsigned char* lk = lds + cur * KV_STAGE_BYTES;
     const unsigned char* lv = lk + 8192;
     cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
@@ -596,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
         float pv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lse_q[qt]));
-        if (need_mask) {
+        if (__builtin_expect(need_mask, 0)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kv0 + kt * 16 + fg * 4 + r;
@@ -604,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
           }
         }
         float dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
-        if (P.drop.thresh8) {
+        if (DROP && P.drop.thresh8) {    // run-time test on purpose, see the forward kernel
           const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
           const unsigned sh = (qrow[qt] & 1) << 4;
           const unsigned kpi = (unsigned)(kv0 + kt * 16 + fg * 4) >> 1;
@@ -632,6 +658,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     }
     }  // wave_active
   }
+  VMCNT(0);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     if (qrow[qt] >= P.Lq) continue;
@@ -726,8 +753,11 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id);
-  if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(attn_grid_x(Lq, 1), H, B), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(attn_grid_x(Lq, 0), H, B), dim3(256), 0, s, P);
+  const dim3 grid(attn_grid_x(Lq, causal), H, B);
+  if (causal && P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, P);
+  else if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, P);
+  else if (P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_fwd");
   return MRMT3_OK;
 }
@@ -750,11 +780,17 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   P.drop = make_attn_drop(p_drop, seed, stream_id);
   hipStream_t s = (hipStream_t)stream;
   // dQ first: it derives delta = rowsum(dO * O) from operands it loads anyway and leaves it for dK/dV
-  if (causal) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(attn_grid_x(Lq, 1), H, B), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(attn_grid_x(Lq, 0), H, B), dim3(256), 0, s, P);
+  const dim3 gq(attn_grid_x(Lq, causal), H, B), gk(attn_grid_x(Lk, causal), H, B);
+  const bool drop = P.drop.thresh8 != 0;
+  if (causal && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, dim3(256), 0, s, P);
+  else if (causal) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), 0, s, P);
+  else if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dq");
-  if (causal) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(attn_grid_x(Lk, 1), H, B), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(attn_grid_x(Lk, 0), H, B), dim3(256), 0, s, P);
+  if (causal && drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, true>), gk, dim3(256), 0, s, P);
+  else if (causal) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, false>), gk, dim3(256), 0, s, P);
+  else if (drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, true>), gk, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, false>), gk, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dkdv");
   return MRMT3_OK;
 }
