@@ -97,8 +97,15 @@ int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const flo
  *          dres / dx1 are f32 or — the residual-gradient stream of the bf16 engine, cols == 512 — bf16
  *   dy   = dropmask_y(dx1) as bf16 (nullable)                      -> dy
  *   dw  += sum_rows g * x1 * rstd      (per-workgroup partials in `workspace`, then a 16-way reduction;
- *                                        workspace >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols)) */
+ *                                        workspace >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols))
+ *   dw == NULL with a workspace: only the partial rows are written; mrmt3_norm_dw_reduce sums the partial rows of
+ *   several such workspaces (one per norm site, all with the same `cols`) into their dw vectors in ONE launch.
+ *   `workspaces` / `dws` are DEVICE arrays of n_sites 64-bit addresses, `partial_rows` a device array of
+ *   mrmt3_add_rmsnorm_bwd_partial_rows(rows of that site).  Same fixed summation order as the immediate form. */
 size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols);
+int mrmt3_add_rmsnorm_bwd_partial_rows(int rows);
+int mrmt3_norm_dw_reduce(const void* workspaces, const void* dws, const int* partial_rows, int n_sites, int cols,
+                         void* stream);
 int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int dres_dtype, const float* x1,
                           const float* rstd, const float* w, void* dx1, int dx1_dtype, void* dy_bf16,
                           float* dw, int rows, int cols,

@@ -215,9 +215,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
 // scratch[chunk]; the chunk workgroup that finishes last (agent-scope counter, zeroed by the norm-backward
 // kernel before) adds the DW_CHUNKS partials in chunk order: no float atomics, bitwise reproducible.
 #define DW_CHUNKS 16
-__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                        int n_part, int cols, float* __restrict__ scratch,
-                                                        int* __restrict__ counters) {
+__device__ __forceinline__ void dw_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int n_part, int cols,
+                                               float* __restrict__ scratch, int* __restrict__ counters) {
   __shared__ float red[4][64];
   __shared__ int last;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
@@ -249,6 +248,32 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
   }
   if (threadIdx.x == 0) counters[blockIdx.x] = 0;
 }
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                        int n_part, int cols, float* __restrict__ scratch,
+                                                        int* __restrict__ counters) {
+  dw_reduce_body(part, dw, n_part, cols, scratch, counters);
+}
+// the same reduction for several norm sites in one launch (blockIdx.z = site): the engine leaves each site's partial
+// rows in a workspace of its own during backward and sums them all when a gradient bucket is about to be sent
+__global__ __launch_bounds__(256) void dw_reduce_sites_kernel(const unsigned long long* __restrict__ ws, const unsigned long long* __restrict__ dws,
+                                                              const int* __restrict__ n_parts, int cols) {
+  const int site = blockIdx.z, n_part = n_parts[site];
+  float* part = (float*)ws[site];
+  float* scratch = part + (size_t)n_part * cols;
+  dw_reduce_body(part, (float*)dws[site], n_part, cols, scratch, (int*)(scratch + (size_t)DW_CHUNKS * cols));
+}
+
+extern "C" int mrmt3_add_rmsnorm_bwd_partial_rows(int rows) { return ceil_div(rows, NB_ROWS); }
+
+extern "C" int mrmt3_norm_dw_reduce(const void* workspaces, const void* dws, const int* partial_rows, int n_sites, int cols,
+                                    void* stream) {
+  MR_CHECK_ARG(workspaces && dws && partial_rows, "norm_dw_reduce: null pointer");
+  MR_CHECK_ARG(n_sites > 0 && n_sites <= 65535 && cols > 0, "norm_dw_reduce: bad sizes");
+  hipLaunchKernelGGL(dw_reduce_sites_kernel, dim3((unsigned)ceil_div(cols, 64), DW_CHUNKS, (unsigned)n_sites), dim3(256), 0,
+                     (hipStream_t)stream, (const unsigned long long*)workspaces, (const unsigned long long*)dws, partial_rows, cols);
+  MR_CHECK_LAUNCH("norm_dw_reduce");
+  return MRMT3_OK;
+}
 
 extern "C" size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols) {
   // per-workgroup partial rows | DW_CHUNKS chunk sums | one arrival counter per 64 columns
@@ -260,11 +285,13 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
                                      float* dw, int rows, int cols,
                                      float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
                                      int out_drop, void* workspace, size_t workspace_bytes, void* stream) {
-  MR_CHECK_ARG(dw == nullptr || (workspace && workspace_bytes >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols)),
+  MR_CHECK_ARG(dw == nullptr || workspace, "add_rmsnorm_bwd: dw needs a workspace");
+  MR_CHECK_ARG(workspace == nullptr || workspace_bytes >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols),
                "add_rmsnorm_bwd: workspace too small");
-  float* dw_part = dw ? (float*)workspace : nullptr;
-  float* dw_scratch = dw ? dw_part + (size_t)ceil_div(rows, NB_ROWS) * cols : nullptr;
-  int* dw_counters = dw ? (int*)(dw_scratch + (size_t)DW_CHUNKS * cols) : nullptr;
+  // workspace without dw: the partial rows are left for mrmt3_norm_dw_reduce (deferred, batched over sites)
+  float* dw_part = (float*)workspace;
+  float* dw_scratch = workspace ? dw_part + (size_t)ceil_div(rows, NB_ROWS) * cols : nullptr;
+  int* dw_counters = workspace ? (int*)(dw_scratch + (size_t)DW_CHUNKS * cols) : nullptr;
   MR_CHECK_ARG(dxn && x1 && rstd && w && dx1, "add_rmsnorm_bwd: null pointer");
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");

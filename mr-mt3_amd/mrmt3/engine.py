@@ -64,6 +64,7 @@ class Engine:
                                os.environ.get("MRMT3_RES_GRAD", "bf16") == "bf16" else torch.float32)
         self._side = None
         self._held = []
+        self.norm_dw = lib.NormDwBatch() if os.environ.get("MRMT3_NORM_DW_BATCH", "1") != "0" else None
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def pos(self, device):
@@ -83,7 +84,7 @@ class Engine:
 
     def side_stream(self):
         if self._side is None or self._side.device != torch.cuda.current_stream().device:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("MRMT3_WGRAD_PRIO", "-1")))
             self._events = [torch.cuda.Event() for _ in range(64)]
             self._ev_i = 0
         return self._side
@@ -103,8 +104,18 @@ class Engine:
         lib.gemm_tn(a, b, out, accumulate=True, stream=side)
         self._held.append((a, b))
 
+    def _norm_bwd(self, *a, **kw):
+        """lib.add_rmsnorm_bwd with the norm-weight gradient deferred to one batched reduction (flush_norm_dw)."""
+        return lib.add_rmsnorm_bwd(*a, defer=self.norm_dw, **kw)
+
+    def flush_norm_dw(self):
+        if self.norm_dw is not None:
+            self.norm_dw.flush()
+
     def join_wgrad(self):
-        """Make the current stream wait for every weight gradient issued so far."""
+        """Make the current stream wait for every weight gradient issued so far (and sum the queued norm-weight
+        gradients: both are what a gradient bucket needs before it is sent)."""
+        self.flush_norm_dw()
         if self.overlap_wgrad and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
             # operands may be recycled now: whatever the current stream does next runs after the side work
@@ -187,7 +198,7 @@ class Engine:
         H, inner, seed = self.H, self.inner, self.seed
         has_y = n_layers > 0
         rg = self.res_grad_dtype if has_y else torch.float32
-        dx, dy = lib.add_rmsnorm_bwd(d_out, None, fin["x1"], fin["rstd"], self.ln(f"{prefix}.final_layer_norm.weight"),
+        dx, dy = self._norm_bwd(d_out, None, fin["x1"], fin["rstd"], self.ln(f"{prefix}.final_layer_norm.weight"),
                                      f.grad(f"{prefix}.final_layer_norm.weight"), want_dy=has_y, p=p, seed=seed,
                                      stream_y=fin["s_in"], stream_out=fin["s_out"], out_drop=True, dx1_dtype=rg)
         for i in reversed(range(n_layers)):
@@ -200,7 +211,7 @@ class Engine:
             dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, stream_id=t["s_g"])
             self.wgrad(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"))
             dxn = lib.gemm_nt(dh, f.WT(f"{prefix}.{i}.wi"), out_dtype=self.y_dtype)
-            dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
+            dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
                                          f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
                                          dx1=dx)
             if ff == 2:
@@ -217,7 +228,7 @@ class Engine:
                 self.wgrad(dkv, enc, f.GW(f"{prefix}.{i}.ckv"))
                 lib.gemm_nt(dkv, f.WT(f"{prefix}.{i}.ckv"), out=d_enc, accumulate=True)
                 dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
-                dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
+                dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
                                              f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
                                              dx1=dx)
             t = tape.pop()
@@ -232,7 +243,7 @@ class Engine:
             self.wgrad(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"))
             dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
             last = i == 0                                     # the stack's input gradient leaves in f32
-            dx, dy = lib.add_rmsnorm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
+            dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
                                          f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed,
                                          stream_y=t["s_in"], dx1=None if (last and dx.dtype != torch.float32) else dx)
             if on_layer_done is not None:
@@ -325,14 +336,14 @@ class Engine:
             pre, b = "segmem_encoder", "segmem_encoder.block.0.layer"
             GW, WT = f.GW(f"{pre}.0.qkv"), f.WT(f"{pre}.0.qkv")
             d_out = d_mem.contiguous().view(B * Ls, d)
-            dx2, dy2 = lib.add_rmsnorm_bwd(d_out, None, t["x2"], t["rstd2"], self.ln(f"{pre}.final_layer_norm.weight"),
+            dx2, dy2 = self._norm_bwd(d_out, None, t["x2"], t["rstd2"], self.ln(f"{pre}.final_layer_norm.weight"),
                                            f.grad(f"{pre}.final_layer_norm.weight"))
             self.wgrad(dy2, t["g"], f.GW(f"{pre}.0.wo"))
             dg = lib.gemm_nt(dy2, f.WT(f"{pre}.0.wo"))
             dh = lib.geglu_bwd(t["h"], dg)
             self.wgrad(dh, t["xn1"], f.GW(f"{pre}.0.wi"))
             dxn1 = lib.gemm_nt(dh, f.WT(f"{pre}.0.wi"), out_dtype=self.y_dtype)
-            dx1, dy = lib.add_rmsnorm_bwd(dxn1, dx2, t["x1"], t["rstd1"], self.ln(f"{b}.1.layer_norm.weight"),
+            dx1, dy = self._norm_bwd(dxn1, dx2, t["x1"], t["rstd1"], self.ln(f"{b}.1.layer_norm.weight"),
                                           f.grad(f"{b}.1.layer_norm.weight"), dx1=dx2)
             self.wgrad(dy, t["o"], f.GW(f"{pre}.0.o"))
             do = lib.gemm_nt(dy, f.WT(f"{pre}.0.o"))
@@ -347,7 +358,7 @@ class Engine:
             dxn_full.view(B, L, d)[:, :Ls] += dxns.view(B, Ls, d)
             dres = torch.zeros(B, L, d, device=dx1.device, dtype=torch.float32)
             dres[:, :Ls] = dx1.view(B, Ls, d)
-            dx, _ = lib.add_rmsnorm_bwd(dxn_full, dres.view(B * L, d), t["x"], t["rstd_full"],
+            dx, _ = self._norm_bwd(dxn_full, dres.view(B * L, d), t["x"], t["rstd_full"],
                                         self.ln(f"{b}.0.layer_norm.weight"), f.grad(f"{b}.0.layer_norm.weight"),
                                         want_dy=False)
         assert t["kind"] == "seg_in"

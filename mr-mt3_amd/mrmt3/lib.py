@@ -32,6 +32,8 @@ _SIGS = {
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
     "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
     "mrmt3_add_rmsnorm_bwd_workspace_bytes": (csz, [ci, ci]),
+    "mrmt3_add_rmsnorm_bwd_partial_rows": (ci, [ci]),
+    "mrmt3_norm_dw_reduce": (ci, [vp, vp, vp, ci, ci, vp]),
     "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp, csz, vp]),
     "mrmt3_attn_fwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
     "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
@@ -247,19 +249,66 @@ def add_rmsnorm_fwd(x0, y, w, eps, xn_dtype, write_x1=True, p=0.0, seed=0, strea
     return (x1 if x1 is not None else x0), xn, rstd
 
 
+class NormDwBatch:
+    """Norm-weight gradients of one backward pass, summed in ONE launch instead of one per norm site.
+
+    `add_rmsnorm_bwd(..., defer=batch)` leaves the site's per-workgroup partial rows in a workspace that belongs to
+    (batch, dw vector, shape) and queues the site; `flush()` runs `mrmt3_norm_dw_reduce` over everything queued
+    (same summation order as the immediate form, so the result is bit-identical).  The caller must flush before the
+    gradients are read (the engine does so before a gradient bucket is sent and at the end of backward).  The address
+    tables live on the device and are rebuilt only when the set of queued sites changes."""
+
+    def __init__(self):
+        self._ws = {}          # (dw address, rows, cols) -> workspace tensor
+        self._queue = []       # [(key, dw tensor)]
+        self._tables = {}      # tuple(keys) -> (ws addresses, dw addresses, partial rows) device tensors
+
+    def site(self, dw, rows, cols):
+        key = (dw.data_ptr(), rows, cols)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.empty(load().mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols), device=dw.device, dtype=torch.uint8)
+            self._ws[key] = ws
+        self._queue.append((key, dw))
+        return ws
+
+    def flush(self):
+        if not self._queue:
+            return
+        for cols in sorted({k[2] for k, _ in self._queue}):
+            keys = tuple(k for k, _ in self._queue if k[2] == cols)
+            tab = self._tables.get(keys)
+            dev = self._queue[0][1].device
+            if tab is None:
+                L = load()
+                tab = (torch.tensor([self._ws[k].data_ptr() for k in keys], dtype=torch.int64, device=dev),
+                       torch.tensor([k[0] for k in keys], dtype=torch.int64, device=dev),
+                       torch.tensor([L.mrmt3_add_rmsnorm_bwd_partial_rows(k[1]) for k in keys], dtype=torch.int32, device=dev))
+                self._tables[keys] = tab
+            _check(load().mrmt3_norm_dw_reduce(_p(tab[0]), _p(tab[1]), _p(tab[2]), len(keys), cols, _stream()),
+                   "norm_dw_reduce")
+        self._queue.clear()
+
+
 def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, stream_y=0, stream_out=0,
-                    out_drop=False, dx1=None, dx1_dtype=torch.float32):
+                    out_drop=False, dx1=None, dx1_dtype=torch.float32, defer=None):
     """`dres` and the returned dx1 may be f32 or bf16 (the bf16 engine's residual-gradient stream); `dx1=`
-    reuses a buffer (in place when it is `dres` itself)."""
+    reuses a buffer (in place when it is `dres` itself).  `defer=` a NormDwBatch: dw is produced by its flush()."""
     _dev(dxn, x1, rstd, w)
     rows, cols = x1.shape
     if dx1 is None:
         dx1 = torch.empty(rows, cols, device=x1.device, dtype=dx1_dtype)
     dy = torch.empty(rows, cols, device=x1.device, dtype=torch.bfloat16) if want_dy else None
-    ws = workspace(load().mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols), x1.device)
+    if dw is None:
+        ws = None
+    elif defer is not None:
+        ws, dw = defer.site(dw, rows, cols), None
+    else:
+        ws = workspace(load().mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols), x1.device)
     _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _dt(dxn), _p(dres), _dt(dres) if dres is not None else F32, _p(x1),
                                         _p(rstd), _p(w), _p(dx1), _dt(dx1), _p(dy), _p(dw), rows, cols, p, seed,
-                                        stream_y, stream_out, int(out_drop), _p(ws), ws.numel(), _stream()),
+                                        stream_y, stream_out, int(out_drop), _p(ws), ws.numel() if ws is not None else 0,
+                                        _stream()),
            "add_rmsnorm_bwd")
     return dx1, dy
 

@@ -240,6 +240,43 @@ def test_add_rmsnorm_fwd_bwd(dev, ydt):
     assert _rel(dw, wr.grad) < 1e-5
 
 
+def test_norm_weight_gradients_batched_over_sites(dev):
+    """`NormDwBatch`: several norm sites leave their partial rows in workspaces of their own and ONE launch sums them
+    (mrmt3_norm_dw_reduce).  Same summation order as the immediate form -> bit-identical, ragged row counts, a second
+    pass accumulates onto the first, and a site that is queued twice before a flush would be a bug we guard against
+    by giving every (dw, shape) its own workspace."""
+    from mrmt3 import lib
+    cols = 512
+    sites = []
+    for i, rows in enumerate((1000, 64 * 256, 37, 4096)):
+        g = torch.Generator(device="cpu").manual_seed(i)
+        x1 = torch.randn(rows, cols, generator=g).to(dev)
+        rstd = (torch.rand(rows, generator=g) + 0.5).to(dev)
+        w = (1 + 0.1 * torch.randn(cols, generator=g)).to(dev)
+        dxn = torch.randn(rows, cols, generator=g).to(dev)
+        sites.append((dxn, x1, rstd, w))
+    want = []
+    for dxn, x1, rstd, w in sites:
+        dw = torch.zeros(cols, device=dev)
+        lib.add_rmsnorm_bwd(dxn, None, x1, rstd, w, dw, want_dy=False)
+        want.append(dw)
+    batch = lib.NormDwBatch()
+    got = [torch.zeros(cols, device=dev) for _ in sites]
+    for (dxn, x1, rstd, w), dw in zip(sites, got):
+        lib.add_rmsnorm_bwd(dxn, None, x1, rstd, w, dw, want_dy=False, defer=batch)
+    assert all(float(d.abs().max()) == 0.0 for d in got)        # nothing is summed before the flush
+    batch.flush()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    for (dxn, x1, rstd, w), dw in zip(sites, got):               # second backward pass: accumulates, tables are reused
+        lib.add_rmsnorm_bwd(dxn, None, x1, rstd, w, dw, want_dy=False, defer=batch)
+    batch.flush()
+    batch.flush()                                                # empty flush is a no-op
+    for (dxn, x1, rstd, w), a, b in zip(sites, got, want):
+        lib.add_rmsnorm_bwd(dxn, None, x1, rstd, w, b, want_dy=False)
+        assert torch.equal(a, b)
+
+
 def test_dropout_sites_consistent(dev):
     """Masks are a pure function of (seed, stream, index): forward and backward agree, keep rate is
     1-p, kept values are scaled by 1/(1-p)."""
