@@ -87,9 +87,13 @@ class GradBuckets:
         assert pos == flat.numel
         self._works = []
         self._fired = set()
-        # called right before a bucket's all-reduce is enqueued; the engine hooks its side-stream join
-        # here (weight gradients are produced on a second stream, see Engine.wgrad)
+        # called right before a bucket's all-reduce is enqueued (the engine sums its queued norm-weight gradients here)
         self.before_fire = None
+        # streams other than the current one that also write gradients (weight gradients are produced on a second
+        # stream, see Engine.wgrad).  The collective is enqueued from a launch stream that waits for the current
+        # stream AND these — the backward pass itself never stops to wait for its own side stream at a bucket boundary.
+        self.producer_streams = None
+        self._launch = None
 
     def reset(self):
         self._works, self._fired = [], set()
@@ -103,8 +107,18 @@ class GradBuckets:
         b = self.buckets[idx]
         if self.before_fire is not None:
             self.before_fire()
-        self._works.append(dist.all_reduce(self.flat.G[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.group,
-                                           async_op=True))
+        grad = self.flat.G[b["start"]:b["end"]]
+        extra = [s for s in (self.producer_streams() if self.producer_streams is not None else []) if s is not None]
+        if grad.is_cuda and extra:
+            if self._launch is None or self._launch.device != grad.device:
+                self._launch = torch.cuda.Stream(device=grad.device)
+            self._launch.wait_stream(torch.cuda.current_stream(grad.device))
+            for s in extra:
+                self._launch.wait_stream(s)
+            with torch.cuda.stream(self._launch):
+                self._works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def on_layer_done(self, prefix, i):
         """Engine callback: every gradient of `prefix` layer i (and above) is final."""

@@ -32,7 +32,8 @@ class Trainer:
         cfg = model.cfg
         self.buckets = GradBuckets(self.flat, cfg["num_layers"], cfg["num_decoder_layers"],
                                    model.segmem_num_layers > 0, layers_per_bucket)
-        self.buckets.before_fire = model.engine.join_wgrad
+        self.buckets.before_fire = model.engine.flush_norm_dw
+        self.buckets.producer_streams = lambda: [model.engine._side]
         self.flat.ensure_grads()
         self.flat.ensure_adam()
         if self.world > 1:   # C2: identical replicas
