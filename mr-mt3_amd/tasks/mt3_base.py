@@ -111,3 +111,39 @@ class MT3Base(_Base):
             'frequency': 1,
         }
         return [optimizer], [schedule]
+
+
+class SegMemTask(MT3Base):
+    """What the three segment-memory tasks share (the reference spells it out once per file,
+    tasks/mt3_net_segmem*.py): the model is built from `MODEL` with the two memory hyper-parameters of the
+    model config, a batch is `(inputs, targets)` plus `targets_prev` when `WITH_PREV`, the loss is the plain
+    token cross-entropy and the optimiser the cosine-with-warm-up AdamW."""
+    MODEL = None
+    WITH_PREV = False
+
+    def __init__(self, config, optim_cfg, eval_cfg=None):
+        super().__init__(config, optim_cfg, eval_cfg=eval_cfg)
+        self.model = self.MODEL(config=self.config, segmem_num_layers=self._cfg("segmem_num_layers", 1),
+                                segmem_length=self._cfg("segmem_length", 64))
+
+    def forward(self, *args, **kwargs):
+        return self.model.forward(*args, **kwargs)
+
+    def _loss(self, batch):
+        from tasks.mt3_net import _ce
+        names = ("inputs", "labels", "targets_prev") if self.WITH_PREV else ("inputs", "labels")
+        fields = dict(zip(names, batch))
+        return _ce(self.forward(**fields), fields["labels"])
+
+    def training_step(self, batch, batch_idx):
+        loss = self._loss(batch)
+        self.log("train_loss", loss, prog_bar=True, on_step=True, on_epoch=False, sync_dist=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        import torch
+        with torch.no_grad():
+            self.log("val_loss", self._loss(batch), prog_bar=True, on_step=False, on_epoch=True, sync_dist=True)
+
+    def configure_optimizers(self):
+        return self._cosine_optimizers()

@@ -1,35 +1,8 @@
-"""`tasks.mt3_net_segmem_v2.MT3NetSegMemV2` — drop-in for tasks/mt3_net_segmem_v2.py:12-64."""
-import torch
-import torch.nn as nn
-
+"""`tasks.mt3_net_segmem_v2.MT3NetSegMemV2` — drop-in for tasks/mt3_net_segmem_v2.py:12-64 (memory appended to the
+encoder states, previous tokens derived from the labels, models/t5_segmem_v2.py)."""
 from models.t5_segmem_v2 import T5SegMemV2
-from tasks.mt3_base import MT3Base
-from tasks.mt3_net import _ce
+from tasks.mt3_base import SegMemTask
 
 
-class MT3NetSegMemV2(MT3Base):
-    def __init__(self, config, optim_cfg, eval_cfg=None):
-        super().__init__(config, optim_cfg, eval_cfg=eval_cfg)
-        self.model: nn.Module = T5SegMemV2(
-            config=self.config,
-            segmem_num_layers=self._cfg("segmem_num_layers", 1),
-            segmem_length=self._cfg("segmem_length", 64),
-        )
-
-    def forward(self, *args, **kwargs):
-        return self.model.forward(*args, **kwargs)
-
-    def training_step(self, batch, batch_idx):
-        inputs, targets = batch
-        loss = _ce(self.forward(inputs=inputs, labels=targets), targets)
-        self.log('train_loss', loss, prog_bar=True, on_step=True, on_epoch=False, sync_dist=True)
-        return loss
-
-    @torch.no_grad()
-    def validation_step(self, batch, batch_idx):
-        inputs, targets = batch
-        loss = _ce(self.forward(inputs=inputs, labels=targets), targets)
-        self.log('val_loss', loss, prog_bar=True, on_step=False, on_epoch=True, sync_dist=True)
-
-    def configure_optimizers(self):
-        return self._cosine_optimizers()
+class MT3NetSegMemV2(SegMemTask):
+    MODEL = T5SegMemV2
