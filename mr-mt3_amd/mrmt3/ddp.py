@@ -11,6 +11,7 @@ the trainer with one more asynchronous collective that nothing on the host waits
 """
 from __future__ import annotations
 
+import os
 from typing import List, Tuple
 
 import torch
@@ -94,6 +95,8 @@ class GradBuckets:
         # stream AND these — the backward pass itself never stops to wait for its own side stream at a bucket boundary.
         self.producer_streams = None
         self._launch = None
+        # single-GPU check of the collective path (profiles/tools/nccl_one_rank_check.py): run the all-reduces at world 1
+        self.force = os.environ.get("MRMT3_DDP_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
 
     def reset(self):
         self._works, self._fired = [], set()
@@ -102,7 +105,7 @@ class GradBuckets:
         if idx in self._fired:
             return
         self._fired.add(idx)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         b = self.buckets[idx]
         if self.before_fire is not None:
