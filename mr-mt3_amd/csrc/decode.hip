@@ -368,10 +368,12 @@ __global__ __launch_bounds__(256) void dec_attn(const float* __restrict__ q, con
 // 8 sequences per workgroup; the workgroup that finishes last (agent-scope counter) folds the finished
 // flags into the "all done" state and advances the step counter — every other workgroup has read it by then.
 __device__ __forceinline__ void dec_step_close(int* state, int B, int p, int t, bool token_step) {
-  __threadfence();
-  const int old = atomicAdd(&state[ST_CNT], 1);
+  // no __threadfence() (on gfx950: write-back + invalidate of the XCD's L2, which would drop the weights the next
+  // step is about to reread): the finished flags are agent-scope atomic stores, complete before the counter is bumped
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int old = __hip_atomic_fetch_add(&state[ST_CNT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (old != (int)gridDim.x - 1) return;
-  state[ST_CNT] = 0;
+  __hip_atomic_store(&state[ST_CNT], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (token_step) {
     int all_done = 1;
     for (int b = 0; b < B; ++b) all_done &= __hip_atomic_load(&state[ST_FLAGS + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(512) void dec_argmax(const float* __restrict__ logi
 #pragma unroll
     for (int c = 0; c < DMODEL / 64; ++c) x[b * DMODEL + c * 64 + lane] = er[c * 64 + lane] + pv[c];
     if (lane == 0) {
-      if (!was_done && nxt == eos) state[ST_FLAGS + b] = 1;
+      if (!was_done && nxt == eos) __hip_atomic_store(&state[ST_FLAGS + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       tokens[(size_t)b * tok_ld + t + 1] = nxt;
     }
   }

@@ -15,7 +15,7 @@ import torch
 
 F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrmt3_hip.so")
+LIB_PATH = os.environ.get("MRMT3_TOOL_LIB") or os.path.join(_HERE, "libmrmt3_hip.so")   # env: A/B a variant build (tuning only)
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "mrmt3_hip.h")
 CSRC_DIR = os.path.join(os.path.dirname(_HERE), "csrc")
 _lib = None
