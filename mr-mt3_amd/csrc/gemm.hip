@@ -297,7 +297,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
                                                          const bf16_t* __restrict__ B, int ldb,
                                                          float* __restrict__ slab, int M, int N1, int N2,
-                                                         int tiles_n2, int n_tiles, int rows_per_split) {
+                                                         int tiles_n2, int n_tiles, int n_splits, int rows_per_split) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TN_ROWS * TN_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -306,15 +306,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   // by all eight.  (blocks with equal blockIdx%8 share an XCD; speed-only assumption.)
   int tile, split;
   {
-    const int nsplit = gridDim.x / n_tiles;
-    if ((nsplit & 7) == 0) {
-      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-      tile = slot % n_tiles;
-      split = xcd + 8 * (slot / n_tiles);
-    } else {
-      tile = blockIdx.x % n_tiles;
-      split = blockIdx.x / n_tiles;
-    }
+    // work items in split-major order (all tiles of token range 0, then of range 1, ...); XCD x (= blockIdx % 8) takes
+    // the contiguous eighth [x*n/8, (x+1)*n/8) of them, in dispatch order.  The grid is padded to a multiple of 8.
+    const int n = (int)gridDim.x, per = n >> 3;
+    const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int n_work = n_tiles * n_splits;
+    if (w >= n_work) return;
+    split = w / n_tiles;
+    tile = w - split * n_tiles;
   }
   const int a0 = (tile / tiles_n2) * TILE, b0 = (tile % tiles_n2) * TILE;
   const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
@@ -438,23 +437,20 @@ static void tn_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_pe
   const int max_s = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps (512 rows) per split
   // 512 workgroups are resident at once (2 per CU): a split count that fills exactly one such wave beats
   // every other choice measured (w_wo 650 -> 785 TF, w_wi 661 -> 698, w_o 394 -> 500), and exactly three
-  // waves beat 1.5 (w_lm 554 -> 604); it must stay <= 8 or a multiple of 8 (one XCD per token range, see kernel)
+  // waves beat 1.5 (w_lm 554 -> 604).  Any count will do for the XCD mapping (contiguous eighths, see kernel).
+  // (a multiple of 8 — whole token ranges per XCD — is preferred when one lies in the efficient range)
   for (int k = 1; k <= 3; ++k)
+    for (int pass = 0; pass < 2; ++pass)
     for (int c = 512 * k / t; c >= 1 && c * t * 100 >= 512 * k * (k == 1 ? 93 : 99); --c)
-      if ((c <= 8 || c % 8 == 0) && c <= max_s && ceil_div(M, ceil_div(steps, c) * TN_ROWS) == c) {
+      if ((pass == 1 || c <= 8 || c % 8 == 0) && c <= max_s && ceil_div(M, ceil_div(steps, c) * TN_ROWS) == c) {
         *tiles = t; *splits = c; *rows_per_split = ceil_div(steps, c) * TN_ROWS;
         return;
       }
   int s = ceil_div(768, t);               // otherwise ~3 workgroups per CU (each split costs a slab round trip)
   s = s < 1 ? 1 : s;
   if (s > max_s) s = max_s;
-  if (s > 8) s = (s + 7) & ~7;            // multiple of 8 -> one XCD per token range (see kernel)
-  if (s > max_s) s = max_s >= 8 ? (max_s & ~7) : max_s;
   int rps = ceil_div(steps, s) * TN_ROWS;
-  if (ceil_div(M, rps) != s) {            // keep the split count exact (and a multiple of 8 when it was)
-    const int s2 = ceil_div(M, rps);
-    s = s2;
-  }
+  s = ceil_div(M, rps);                   // keep the split count exact
   *tiles = t; *splits = s; *rows_per_split = rps;
 }
 
@@ -474,8 +470,8 @@ extern "C" int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, flo
   tn_plan(M, N1, N2, &tiles, &splits, &rps);
   MR_CHECK_ARG(workspace_bytes >= (size_t)splits * N1 * N2 * sizeof(float), "gemm_tn: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, (float*)workspace, M, N1, N2, ceil_div(N2, TILE), tiles, rps);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((tiles * splits + 7) & ~7)), dim3(256), 0, s, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, (float*)workspace, M, N1, N2, ceil_div(N2, TILE), tiles, splits, rps);
   MR_CHECK_LAUNCH("gemm_tn");
   const size_t n = (size_t)N1 * N2;
   int blocks = (int)((n / 4 + 255) / 256);
