@@ -18,7 +18,10 @@ Md, Me = 65536, 16384
 NT = [("qkv", Md, 1152, 512, "bf16"), ("o", Md, 512, 384, "f32"), ("cq", Md, 384, 512, "bf16"),
       ("ckv", Me, 768, 512, "bf16"), ("wi", Md, 2048, 512, "bf16"), ("wo", Md, 512, 1024, "f32"),
       ("lm_head", Md, 1536, 512, "f32"), ("d_qkv", Md, 512, 1152, "f32"), ("d_wi", Md, 512, 2048, "f32"),
-      ("d_wo", Md, 1024, 512, "bf16"), ("d_o", Md, 384, 512, "bf16")]
+      ("d_wo", Md, 1024, 512, "bf16"), ("d_o", Md, 384, 512, "bf16"),
+      ("e_qkv", Me, 1152, 512, "bf16"), ("e_o", Me, 512, 384, "f32"), ("e_wi", Me, 2048, 512, "bf16"),
+      ("e_wo", Me, 512, 1024, "f32"), ("e_dqkv", Me, 512, 1152, "f32"), ("e_dwi", Me, 512, 2048, "f32"),
+      ("e_dwo", Me, 1024, 512, "bf16"), ("e_do", Me, 384, 512, "bf16")]
 TN = [("w_qkv", Md, 1152, 512), ("w_o", Md, 512, 384), ("w_cq", Md, 384, 512), ("w_wi", Md, 2048, 512),
       ("w_wo", Md, 512, 1024), ("w_lm", Md, 1536, 512), ("w_ckv", Me, 768, 512), ("e_qkv", Me, 1152, 512),
       ("e_o", Me, 512, 384), ("e_wi", Me, 2048, 512), ("e_wo", Me, 512, 1024)]
