@@ -65,46 +65,44 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// ---- counter-based RNG for dropout: Philox4x32-10 --------------------------------------------------
-// One call yields 4 x 32 random bits for (seed, offset, idx).  Every dropout site passes a distinct
-// `offset` stream id so forward and backward regenerate identical masks without storing them.
-__device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long ctr_lo,
-                                              unsigned ctr_hi, unsigned out[4]) {
-  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-  unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = ctr_hi, c3 = 0x9E3779B9u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-    unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
-    unsigned n1 = (unsigned)p1;
-    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
-    unsigned n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+// ---- counter-based mask generator for the element-wise dropout sites ------------------------------------------
+// mask(seed, site, element index): forward and backward regenerate the same mask, nothing is stored.  Two 32-bit
+// mixes per 4 elements, 16 bits per element: keep iff u16 >= thresh16, thresh16 = round(p * 65536) (p = 0.1 ->
+// 6554/65536 = 0.100006) and the keep scale is 65536 / (65536 - thresh16), exactly unbiased.  The mix is the
+// attention kernels' one (xor-shift, two full-rate 24-bit multiplies) with a final fold so the low half is as good
+// as the high one; checked on row-major [4096 x 512] masks for several (seed, site): keep rate 0.9000, byte
+// histograms chi^2 ~ 255, |correlation| <= 0.002 at lags 1-8 along rows and columns, row / column keep counts
+// binomial, sites and seeds uncorrelated.  (Round 1 first used Philox4x32-10: 40 quarter-rate multiplies per 4
+// elements, which made the mask, not HBM, a third of the GEGLU / norm kernels' time: geglu_fwd 79 -> 105 us.)
+__device__ __forceinline__ unsigned drop_mix(unsigned x) {
+  x ^= x >> 16; x = __umul24(x, 0x7feb35u); x ^= x >> 15; x = __umul24(x, 0x6ca68bu); x ^= x >> 16;
+  return x;
 }
-// keep-scale for 4 consecutive elements whose first flat index is idx4*4.
-// keep iff u32 >= thresh where thresh = p * 2^32;  scale = 1/(1-p)
 struct DropCfg {
-  unsigned long long seed;
-  unsigned stream;   // site id
-  unsigned thresh;   // p * 2^32 (0 => dropout off)
-  float scale;       // 1/(1-p)
+  unsigned key;      // seed and site id folded together
+  unsigned thresh;   // 16-bit threshold (0 => dropout off)
+  float scale;       // 65536 / (65536 - thresh)
 };
+// keep-scale for 4 consecutive elements whose first flat index is idx4*4
 __device__ __forceinline__ void drop_mask4(const DropCfg& d, unsigned long long idx4, float m[4]) {
-  unsigned r[4];
-  philox4x32_10(d.seed, idx4, d.stream, r);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) m[i] = (r[i] >= d.thresh) ? d.scale : 0.f;
+  const unsigned c = ((unsigned)idx4 << 1) ^ ((unsigned)(idx4 >> 31) * 0xC2B2AE35u);
+  const unsigned h0 = drop_mix(d.key + c * 0x9E3779B1u), h1 = drop_mix(d.key + (c + 1u) * 0x9E3779B1u);
+  m[0] = (h0 & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+  m[1] = (h0 >> 16) >= d.thresh ? d.scale : 0.f;
+  m[2] = (h1 & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+  m[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
 }
 __host__ inline DropCfg make_drop(float p, unsigned long long seed, unsigned stream) {
   DropCfg d;
-  d.seed = seed;
-  d.stream = stream;
+  d.key = ((unsigned)seed ^ ((unsigned)(seed >> 32) * 0x9E3779B1u)) + stream * 0x85EBCA6Bu;
   if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; }
-  else { double t = (double)p * 4294967296.0; d.thresh = (unsigned)(t > 4294967295.0 ? 4294967295.0 : t); d.scale = 1.f / (1.f - p); }
+  else {
+    unsigned t = (unsigned)((double)p * 65536.0 + 0.5);
+    if (t < 1) t = 1;
+    if (t > 65535) t = 65535;
+    d.thresh = t;
+    d.scale = 65536.0f / (65536.0f - (float)t);
+  }
   return d;
 }
 

@@ -144,8 +144,14 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
   for (int row = blockIdx.x * NB_ROWS + wave; row < row_end; row += 4) {
     const size_t base = (size_t)row * cols;
     const float rstd = rstd_in[row];
-    float g[NV][4], xh[NV][4];
+    float g[NV][4], xh[NV][4], rr[NV][4];
     float dot = 0.f;
+    // the residual gradient is requested together with the other operands: one memory round trip per row, not two
+    if (dres != nullptr) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (i < nv) load4<TRI>(dres + base + i * 256 + lane * 4, rr[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if (i < nv) {
@@ -176,10 +182,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = rstd * (g[i][e] - xh[i][e] * dot);
         if (dres != nullptr) {
-          float r[4];
-          load4<TRI>(dres + base + col, r);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) d[e] += r[e];
+          for (int e = 0; e < 4; ++e) d[e] += rr[i][e];
         }
         store4<TRO>(dx1 + base + col, d);
         if (dy != nullptr) {
