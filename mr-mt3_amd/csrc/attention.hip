@@ -423,9 +423,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
     const float* lstat = (const float*)(lq + 8192);   // [0..31] lse, [32..63] delta
     cur = cur == QD_STAGES - 1 ? 0 : cur + 1;
     // causal: a query block entirely above this wave's 32 keys contributes nothing to them
-    const bool wave_active = !(P.causal && qb0 + 31 < k0 + uw * 32);
+    // ... and a wave whose 32 keys all lie past the end of the sequence (ragged last key tile, e.g. 256 encoder
+    // frames + 64 memory slots = 320 keys) has nothing to compute at all
+    const bool wave_active = (k0 + uw * 32 < P.Lk) && !(P.causal && qb0 + 31 < k0 + uw * 32);
     if (wave_active) {
-    const bool need_mask = (qb0 + 32 > P.Lq) || (k0 + 128 > P.Lk) || (P.causal && qb0 < k0 + uw * 32 + 31);
+    const bool need_mask = (qb0 + 32 > P.Lq) || (k0 + uw * 32 + 32 > P.Lk) || (P.causal && qb0 < k0 + uw * 32 + 31);
     bf16x8 pdB[2], dsB[2];  // per key tile: B operands built from both query tiles
     f32x4 pd[2][2], ds[2][2];  // [qt][nt]
 #pragma unroll
