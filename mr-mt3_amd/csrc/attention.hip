@@ -7,7 +7,7 @@
 //
 // bf16 kernels are flash-style (never materialise [B,H,Lq,Lk]); fp32 softmax statistics.
 //   forward : workgroup = 128 query rows of one (batch, head); 4 waves x 32 rows.  K/V tiles of 64
-//             keys go HBM->LDS directly (global_load_lds, 3 stages, two tiles in flight across a raw
+//             keys go memory->LDS directly (buffer_load ... lds, 3 stages, two tiles in flight across a raw
 //             s_barrier with counted vmcnt); 128-B LDS rows with XOR-swizzled 16-B chunks are
 //             conflict-free for both ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads.
 //             The scores are computed TRANSPOSED (S^T = K.Q^T, query on the MFMA lane) so that the
@@ -17,6 +17,9 @@
 //             delta = rowsum(dO*O) from operands it holds anyway and stores it; (2) dK/dV: workgroup = 128
 //             keys, key on the lane, loops over 32-query blocks.  P is recomputed from the saved log-sum-exp.  No atomics: every output
 //             element has exactly one writer, results are bitwise reproducible.
+//   launch  : every tile of one (batch, head) runs on ONE XCD (attn_tile), causal launches give each workgroup the
+//             tile pair (n-1-t, t) so all workgroups are equal, and VALU work is kept to a minimum because VALU and
+//             MFMA instructions do not overlap on a gfx950 SIMD.
 // The f32 kernel is a plain exact-f32 implementation used for the fp32 parity / greedy-decode path.
 #include "common.h"
 
@@ -101,17 +104,10 @@ struct AttnParams {
 };
 
 // ---- LDS tiles: [rows][64] bf16 = 128-B rows, the 16-B chunk index XOR-ed with (row & 7).  Tiles are
-// filled by global_load_lds_dwordx4 (HBM -> LDS, no VGPR round trip): one wave-instruction covers 8
-// rows x 128 B linearly, so the swizzle is applied to each lane's SOURCE chunk.  The same image
+// filled by buffer_load ... lds (memory -> LDS, no VGPR round trip, see blds_rows8 below): one wave-instruction
+// covers 8 rows x 128 B linearly, so the swizzle is applied to each lane's SOURCE chunk.  The same image
 // serves ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads, both conflict-free.
-// Rows past the end of the tensor are clamped to the last valid row (their scores are masked).
-__device__ __forceinline__ void glds_rows8(const bf16_t* base, int ld, int row0, int nrows_valid, unsigned char* dst,
-                                           int lane) {
-  const int r = min(row0 + (lane >> 3), nrows_valid - 1);
-  const int c = (lane & 7) ^ (lane >> 3);
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)r * ld + c * 8),
-                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-}
+// Rows past the end of the tensor are zero-filled by the buffer bounds check (their scores are masked).
 __device__ __forceinline__ bf16x8 lds_row8(const unsigned char* tile, int row, int c) {
   return *(const bf16x8*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
 }
