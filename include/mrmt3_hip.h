@@ -198,7 +198,8 @@ int mrmt3_transpose_batched(const void* src_bf16, void* dst_bf16, const void* de
  * segment).  The decoder handle owns: the captured graph, the self-attention KV cache
  * [layers][2][B][max_len][H*64], scratch activations and the device-side step/finished state.
  * Weights are referenced, not copied: `weights` is an array of mrmt3_decoder_weights (device
- * pointers into the caller's flat parameter buffer, dtype = act dtype of the handle). */
+ * pointers into the caller's flat parameter buffer, dtype = act dtype of the handle).
+ * max_batch <= 256 sequences per handle (d_model 512, heads*64 <= 512, d_ff <= 1024). */
 typedef struct mrmt3_decoder mrmt3_decoder;
 typedef struct {
   const void* embed;        /* [vocab][d] f32 decoder_embed_tokens */

@@ -13,14 +13,14 @@
 // interaction; the host polls an 12-byte status block only when it wants to stop early.
 // A step is a chain of dependent launches (1.77 us each at best on this runtime), so every kernel is built to be
 // short rather than frugal: up to 8 sequences run one weight row x one sequence per wave (batch on gridDim.y;
-// the re-read of a weight row by the other sequences is an L2 hit), larger batches (<= 64) multiply 16 rows by
+// the re-read of a weight row by the other sequences is an L2 hit), larger batches (<= 256) multiply 16 rows by
 // 16 sequences on the matrix cores with K split over a workgroup; the 45.6 MB (bf16) of per-step weights stay
 // resident in the 256 MB Infinity Cache.  mrmt3_decoder_set_prefix feeds memory rows before the start token
 // (the V1 segment-memory decode).
 #include "common.h"
 
 #define DMODEL 512
-#define DEC_MAXB 64
+#define DEC_MAXB 256
 #ifndef DEC_MFMA_ABOVE
 #define DEC_MFMA_ABOVE 8   // batches larger than this use the 16-sequence MFMA projections (bf16 weights)
 #endif
@@ -455,7 +455,7 @@ __global__ void dec_prefix_kernel(int B, int n_prefix, const float* prefix, cons
 __global__ void dec_begin_kernel(int B, int64_t* tokens, int tok_ld, const float* embed, const float* pos, float* x,
                                  int* state, int start_id) {
   const int tid = threadIdx.x;
-  if (tid <= ST_CNT) state[tid] = (tid == ST_FIN) ? -1 : 0;
+  for (int i = tid; i <= ST_CNT; i += (int)blockDim.x) state[i] = (i == ST_FIN) ? -1 : 0;
   for (int b = 0; b < B; ++b) {
     if (tid == 0) tokens[(size_t)b * tok_ld] = start_id;
     x[b * DMODEL + tid] = embed[(size_t)start_id * DMODEL + tid] + pos[tid];
@@ -489,7 +489,7 @@ extern "C" int mrmt3_decoder_create(mrmt3_decoder** out, int n_layers, int d_mod
   MR_CHECK_ARG(out, "decoder_create: null out");
   *out = nullptr;
   MR_CHECK_ARG(d_model == DMODEL, "decoder_create: kernels are specialised for d_model = 512");
-  MR_CHECK_ARG(n_layers > 0 && n_layers <= 64 && max_batch > 0 && max_batch <= DEC_MAXB, "decoder_create: need 1..64 layers, batch <= 64");
+  MR_CHECK_ARG(n_layers > 0 && n_layers <= 64 && max_batch > 0 && max_batch <= DEC_MAXB, "decoder_create: need 1..64 layers, batch <= 256");
   MR_CHECK_ARG(d_ff % 8 == 0 && d_ff <= 1024 && n_heads * 64 <= 512 && vocab > 0 && max_len > 0 && max_enc_len > 0, "decoder_create: need d_ff <= 1024, heads*64 <= 512");
   MR_CHECK_ARG(w_dtype == MRMT3_F32 || w_dtype == MRMT3_BF16, "decoder_create: bad dtype");
   mrmt3_decoder* D = new mrmt3_decoder();

@@ -18,7 +18,7 @@ import torch
 from . import lib
 
 
-MAX_DECODE_BATCH = 64      # DEC_MAXB of csrc/decode.hip: sequences decoded together (one wave per row x sequence)
+MAX_DECODE_BATCH = 256     # DEC_MAXB of csrc/decode.hip: sequences decoded together (one wave per row x sequence)
 
 
 class _Weights(C.Structure):

@@ -356,6 +356,34 @@ def test_greedy_large_batch_equals_small_groups(dev):
     assert torch.equal(big, small)
 
 
+@pytest.mark.parametrize("dtype,n,group", [(torch.float32, 150, 64), (torch.bfloat16, 200, 100)])
+def test_greedy_groups_beyond_64_sequences(dev, dtype, n, group):
+    """The decoder takes up to 256 sequences per group (19 / 25 argmax workgroups, several MFMA column groups): the token
+    ids of one large group equal those of the same segments decoded in smaller groups, early EOS included."""
+    import mrmt3.decode as dec_mod
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel
+    w = golden_weights(T5_SMALL)
+    w["lm_head.weight"] = w["lm_head.weight"].copy()
+    w["lm_head.weight"][1] *= 3.2
+    m = _build("t5", dtype, dev)
+    with torch.no_grad():
+        m.flat.load_numpy(w)
+    mel = torch.from_numpy(synth_mel(n, seed=33)).to(dev)
+    if dtype == torch.bfloat16:
+        mel = mel.bfloat16()
+    big = m.generate(mel, max_length=48)
+    assert big.shape[0] == n and dec_mod.MAX_DECODE_BATCH >= n
+    old = dec_mod.MAX_DECODE_BATCH
+    try:
+        dec_mod.MAX_DECODE_BATCH = group
+        m._decoder = None
+        small = m.generate(mel, max_length=48)
+    finally:
+        dec_mod.MAX_DECODE_BATCH = old
+        m._decoder = None
+    assert torch.equal(big, small)
+
+
 def test_bf16_large_batch_mfma_projections_agree_with_single_sequence_kernels(dev):
     """Batches > 8 run the decode projections on the matrix cores, 16 sequences per wave.  Both paths use
     bf16 operands and f32 accumulation, so they may differ only by the order of additions: over the first
