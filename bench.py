@@ -169,7 +169,7 @@ def inference_rtf(dev, tokens, batch):
     with torch.no_grad():
         mm.flat.master("lm_head.weight")[1].zero_()
     n_seg = 3
-    for name, n_songs in (("mrmt3_1song", 1), ("mrmt3_8songs", 8)):
+    for name, n_songs in (("mrmt3_1song", 1), ("mrmt3_8songs", 8), ("mrmt3_64songs", 64)):
         songs = [sp.logmel_segments(audio[i * n_seg:(i + 1) * n_seg], out_bf16=True) for i in range(n_songs)]
         for rep in range(2):
             torch.cuda.synchronize()
