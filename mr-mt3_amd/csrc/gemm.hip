@@ -422,8 +422,18 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   const size_t n = (size_t)N1 * N2;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
        i += (size_t)gridDim.x * blockDim.x * 4) {
+    // eight slabs requested before the first is added (same summation order, so the result is unchanged): the kernel
+    // is a few hundred small workgroups and lives on how many loads each thread keeps in flight
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; ++k) s += *(const f32x4*)(slab + (size_t)k * n + i);
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(slab + (size_t)(k + u) * n + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += *(const f32x4*)(slab + (size_t)k * n + i);
     const int row = (int)(i / N2), col = (int)(i % N2);
     float* p = C + (size_t)row * ldc + col;
     if (accumulate) s += *(const f32x4*)p;
