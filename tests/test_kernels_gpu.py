@@ -277,6 +277,18 @@ def test_norm_weight_gradients_batched_over_sites(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("p,seed,stream", [(0.1, 1234, 5), (0.3, 2 ** 40 + 17, 1), (0.1, 2 ** 63 + 5, 200)])
+def test_dropout_mask_equals_the_restatement_bit_for_bit(dev, p, seed, stream):
+    """csrc/common.h drop_mask4 == oracle/dropout_ref.keep_mask: same kept elements, same keep scale."""
+    from mrmt3 import lib
+    from oracle import dropout_ref as dr
+    rows, cols = 777, 512
+    out = lib.dropmask_cast(torch.ones(rows, cols, device=dev), p=p, seed=seed, stream_id=stream).float().cpu().numpy().reshape(-1)
+    keep, scale = dr.keep_mask(rows * cols, p, seed, stream)
+    assert ((out != 0) == keep).all()
+    assert abs(float(out[keep][0]) - scale) < 8e-3 * scale        # bf16 output
+
+
 def test_dropout_sites_consistent(dev):
     """Masks are a pure function of (seed, stream, index): forward and backward agree, keep rate is
     1-p, kept values are scaled by 1/(1-p)."""
@@ -399,6 +411,34 @@ def test_attn_dropout_statistics_and_bwd_mask(dev, B, H, L, causal):
     assert torch.allclose(s_o, s_dv, rtol=3e-3)
     # uniform scores: dS = P * (dP - delta) with dP = mask/0.9 row-constant only up to the mask -> dq, dk stay finite
     assert torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all()
+
+
+@pytest.mark.parametrize("B,H,Lq,causal", [(2, 3, 200, False), (1, 2, 64, True)])
+def test_attn_dropout_mask_equals_the_restatement(dev, B, H, Lq, causal):
+    """Uniform scores and V = identity over 64 keys make the output the dropped probability matrix itself:
+    O[q, k] = keep[q, k] * scale / (#visible keys).  The kept set must equal oracle/dropout_ref.attn_keep_mask, and
+    dV = Pd^T dO must come from the same mask in the backward kernels."""
+    from mrmt3 import lib
+    from oracle import dropout_ref as dr
+    Lk, p, seed, stream = 64, 0.1, 2 ** 35 + 99, 7
+    q = torch.zeros(B * Lq, H * 64, device=dev).bfloat16()
+    k = torch.zeros(B * Lk, H * 64, device=dev).bfloat16()
+    v = torch.eye(64, device=dev).repeat(B, H).bfloat16()                     # [B*64, H*64]: V_h = I for every (b, h)
+    o, lse = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=p, seed=seed, stream_id=stream)
+    keep, scale = dr.attn_keep_mask(B, H, Lq, Lk, p, seed, stream)
+    got = o.float().view(B, Lq, H, 64).permute(0, 2, 1, 3).cpu().numpy()     # [B, H, Lq, Lk]
+    qi = torch.arange(Lq).view(Lq, 1).numpy(); ki = torch.arange(Lk).view(1, Lk).numpy()
+    visible = (ki <= qi) if causal else (ki >= 0) & (qi >= 0)
+    n_vis = visible.sum(1, keepdims=True)
+    want = (keep & visible) * (scale / n_vis)
+    assert ((got != 0) == (keep & visible)).all()
+    assert abs(got - want).max() < 1e-2 * want.max()
+    d_o = torch.ones_like(o)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal, p=p, seed=seed, stream_id=stream)
+    dv_want = want.sum(2)                                                      # [B, H, Lk]: sum_q Pd[q, k]
+    dv_got = dv.float().view(B, Lk, H, 64)[..., 0].permute(0, 2, 1).cpu().numpy()
+    assert abs(dv_got - dv_want).max() < 2e-2 * max(1.0, dv_want.max())
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 6, 256, 256, False), (1, 6, 128, 128, True), (1, 6, 100, 320, False)])
