@@ -384,10 +384,11 @@ def test_attn_online_softmax_rescale_branch(dev):
     assert torch.allclose(lse, lref, atol=5e-3, rtol=1e-4) and _rel(o, oref) < 1e-2
 
 
-@pytest.mark.parametrize("B,H,L,causal", [(1, 2, 256, False), (2, 4, 512, True), (1, 3, 384, True)])
+@pytest.mark.parametrize("B,H,L,causal", [(1, 2, 256, False), (2, 4, 512, True), (1, 3, 384, True), (64, 6, 1024, True)])
 def test_attn_dropout_statistics_and_bwd_mask(dev, B, H, L, causal):
     """Uniform attention (q = k = 0, v = 1): every output is (#kept / #visible) / 0.9.  The causal cases run the
-    paired-tile instantiations (an even and an odd number of 128-row tiles, with and without the XCD remap)."""
+    paired-tile instantiations (an even and an odd number of 128-row tiles, with and without the XCD remap); the last
+    case is the decoder self-attention of the benchmark batch at full size."""
     from mrmt3 import lib
     q = torch.zeros(B * L, H * 64, device=dev).bfloat16()          # uniform attention
     k = torch.zeros(B * L, H * 64, device=dev).bfloat16()
