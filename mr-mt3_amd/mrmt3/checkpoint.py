@@ -123,10 +123,15 @@ def lightning_checkpoint(model, trainer=None, epoch: int = 0) -> dict:
     optimizer + scheduler state so that the reference's `trainer.fit(ckpt_path=...)` can resume)."""
     sd = OrderedDict((LIGHTNING_PREFIX + k, v.detach().cpu().clone()) for k, v in model.state_dict().items())
     out = {"epoch": epoch, "global_step": 0, "pytorch-lightning_version": "1.9.0", "state_dict": sd,
-           "loops": {}, "callbacks": {}, "optimizer_states": [], "lr_schedulers": []}
+           "callbacks": {}, "optimizer_states": [], "lr_schedulers": []}
+    # no "loops" key: Lightning's restore_loops() reads state_dict["fit_loop"] whenever the key exists, so an empty
+    # dict would raise; without it the loops start fresh and `global_step` comes from the optimizer step counts
     if trainer is not None:
         order = reference_parameter_order(model.cfg, model.segmem_num_layers)
-        lr_now = float(trainer.lr_dev.item())
+        # torch's LambdaLR holds lambda(N) after N optimizer steps (the lr the NEXT step uses); trainer.lr_dev still
+        # holds the lr of the last executed step
+        lr_now = (trainer.base_lr * trainer.lr_lambda(trainer.host_step) if trainer.lr_lambda is not None
+                  else float(trainer.lr_dev.item()))
         opt = adamw_state_from_flat(model.flat, order, trainer.host_step, lr_now, trainer.betas, trainer.eps,
                                     trainer.wd, initial_lr=trainer.base_lr)
         for s in opt["state"].values():

@@ -88,6 +88,7 @@ class MT3Module(nn.Module):
             p = nn.Parameter(self.flat.master(key))
             self._views[key] = p
             self._register(key, p)
+        self.flat.version_sources = tuple(self._views.values())
         # aliases: the stacks' embed_tokens ARE proj / decoder_embed_tokens / segmem_proj (t5.py:64,70)
         self._register("encoder.embed_tokens.weight", self._views["proj.weight"])
         self._register("decoder.embed_tokens.weight", self._views["decoder_embed_tokens.weight"])

@@ -41,6 +41,10 @@ class FlatParams:
         self.S = None          # bf16 shadow of P
         self.ST = None         # pre-transposed bf16 weights for dgrad
         self._shadow_version = -1
+        # tensors other than P whose in-place updates also change the master (the nn.Parameter views of
+        # MT3Module: after `.to(device)` each owns a version counter of its own, so torch.optim / load_state_dict
+        # writes do not bump P._version)
+        self.version_sources = ()
         self._build_groups(segmem_num_layers)
 
     # ---- fused weight groups ------------------------------------------------------------------------
@@ -135,11 +139,18 @@ class FlatParams:
             self.M = torch.zeros_like(self.P)
             self.V = torch.zeros_like(self.P)
 
+    def master_version(self):
+        """Changes whenever the master weights were written through P or through any registered view."""
+        v = self.P._version
+        for t in self.version_sources:
+            v += t._version
+        return v
+
     def refresh_shadows(self, force=False, need_transposed=True):
         """(Re)build the bf16 shadow and the transposed dgrad copies when the master changed."""
         if not self.P.is_cuda:
             raise RuntimeError("bf16 shadows live on the GPU (no CPU fallback)")
-        ver = self.P._version
+        ver = self.master_version()
         have_t = self.ST is not None
         if not force and self.S is not None and ver == self._shadow_version and (have_t or not need_transposed):
             return
@@ -181,7 +192,7 @@ class FlatParams:
         lib.adamw_step(self.P, self.G, self.M, self.V, lr_dev, step_dev, betas[0], betas[1], eps, weight_decay,
                        grad_scale, shadow=self.S)
         self.refresh_transposed()
-        self._shadow_version = self.P._version
+        self._shadow_version = self.master_version()
 
     def load_numpy(self, weights: dict):
         for k, v in weights.items():

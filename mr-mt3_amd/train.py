@@ -9,10 +9,14 @@ one process per GPU:
         model=MT3NetSegMemV2WithPrev dataset=SlakhPrevAugment +synthetic=True +max_steps=100
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...      # data parallel
 
-Real Slakh/ComMU datasets need the reference's `dataset/` package and its third-party stack
-(librosa, note_seq, ...: out of scope); when it is importable the configured
-`cfg.dataset.train._target_` is used as is, otherwise (or with `+synthetic=True`) synthetic
-Slakh-shaped batches exercise the same shapes.
+Data.  With `+synthetic=True` the loop runs `+max_steps` (default 10) synthetic Slakh-shaped batches (raw audio,
+log-mel on the GPU).  Without it the configured `cfg.dataset.train` / `cfg.dataset.val` are instantiated and wrapped
+in `torch.utils.data.DataLoader(**cfg.dataloader.*, collate_fn=cfg.dataset.collate_fn)` exactly like
+`train.py:48-59`: batches are the reference's `(inputs mel, targets[, targets_prev])` tuples, the run lasts
+`num_epochs` epochs (or `+max_steps`), and `val_loss` is evaluated every `trainer.check_val_every_n_epoch` epochs.
+The Slakh/ComMU dataset classes themselves are the reference's `dataset/` package (librosa, note_seq, ...: out of
+scope): put it on PYTHONPATH.  If it cannot be imported the driver STOPS with that message — it
+never silently substitutes synthetic data.
 
 `cfg.path` has the reference's meaning (`train.py:61-92`): a `.ckpt` resumes weights, AdamW moments and
 the step counter; a `.pth` only loads weights (`strict=False`); anything else is an error.  At the end
@@ -46,6 +50,38 @@ def synthetic_batches(cfg, rank, device, steps, with_prev):
         yield audio, labels, prev
 
 
+def real_loaders(cfg):
+    """DataLoaders over the configured datasets (train.py:48-59).  Raises with a clear message when the dataset
+    package (the reference's `dataset/`, not part of this path) cannot be imported."""
+    from torch.utils.data import DataLoader
+    try:
+        train_set = hydra_lite.instantiate(cfg.dataset.train)
+        val_set = hydra_lite.instantiate(cfg.dataset.val)
+        collate = hydra_lite.get_method(str(cfg.dataset.collate_fn))
+    except ImportError as e:
+        raise RuntimeError(
+            f"cannot instantiate cfg.dataset ({cfg.dataset.train.get('_target_')}): {e}.  The dataset classes are the "
+            "reference's `dataset/` package (needs librosa / note_seq): put it on PYTHONPATH, or pass +synthetic=True "
+            "to run synthetic Slakh-shaped batches.") from e
+    kw_t = {k: v for k, v in dict(cfg.dataloader.train).items()}
+    kw_v = {k: v for k, v in dict(cfg.dataloader.val).items()}
+    return (DataLoader(train_set, collate_fn=collate, **kw_t), DataLoader(val_set, collate_fn=collate, **kw_v))
+
+
+def loader_batches(loader, device, epochs, max_steps):
+    """(epoch, inputs, targets, targets_prev) from the reference's collated batches, moved to the device."""
+    n = 0
+    for ep in range(epochs):
+        for batch in loader:
+            if max_steps is not None and n >= max_steps:
+                return
+            inputs, targets = batch[0], batch[1]
+            prev = batch[2] if len(batch) > 2 else None
+            yield ep, inputs.to(device, non_blocking=True), targets.to(device, non_blocking=True), \
+                (None if prev is None else prev.to(device, non_blocking=True))
+            n += 1
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config-dir", "--config-path", dest="config_dir", required=True)   # both spellings appear in the reference's scripts
@@ -73,7 +109,12 @@ def main(argv=None):
     trainer = Trainer(task.model, lr=float(cfg.optim.lr), lr_lambda=lam,
                       weighted_loss=type(task).__name__ == "MT3NetWeightedLoss")
     with_prev = "WithPrev" in type(task).__name__
-    steps = int(cfg.get("max_steps", 10))
+    synthetic = bool(cfg.get("synthetic", False))
+    max_steps = cfg.get("max_steps")
+    max_steps = None if max_steps is None else int(max_steps)
+    train_loader = val_loader = None
+    if not synthetic:
+        train_loader, val_loader = real_loaders(cfg)
     start = 0
     path = cfg.get("path")
     if path is not None and str(path) != "":
@@ -88,10 +129,35 @@ def main(argv=None):
             trainer.resume(path)
         else:
             raise ValueError(f"Invalid extension for path: {path}")
-    for it, (audio, labels, prev) in enumerate(synthetic_batches(cfg, rank, device, steps, with_prev), start):
-        loss = trainer.train_step(audio, labels, prev, audio=True)
-        if rank == 0 and (it % max(1, int(cfg.trainer.get("log_every_n_steps", 100))) == 0 or it == start + steps - 1):
-            print(f"step {it} train_loss {loss.item():.4f}", flush=True)
+    log_every = max(1, int(cfg.trainer.get("log_every_n_steps", 100)))
+    if synthetic:
+        steps = 10 if max_steps is None else max_steps
+        for it, (audio, labels, prev) in enumerate(synthetic_batches(cfg, rank, device, steps, with_prev), start):
+            loss = trainer.train_step(audio, labels, prev, audio=True)
+            if rank == 0 and (it % log_every == 0 or it == start + steps - 1):
+                print(f"step {it} train_loss {loss.item():.4f}", flush=True)
+    else:
+        val_every = max(1, int(cfg.trainer.get("check_val_every_n_epoch", 1)))
+        it, last_ep, loss = start, 0, None
+
+        def validate(ep):
+            tot, n = 0.0, 0
+            for b in val_loader:
+                prev = b[2].to(device) if len(b) > 2 else None
+                tot += float(trainer.eval_loss(b[0].to(device), b[1].to(device), prev).item())
+                n += 1
+            if rank == 0 and n:
+                print(f"epoch {ep} val_loss {tot / n:.4f}", flush=True)
+
+        for ep, mel, labels, prev in loader_batches(train_loader, device, int(cfg.num_epochs), max_steps):
+            if ep != last_ep and ep % val_every == 0:
+                validate(last_ep)
+            last_ep = ep
+            loss = trainer.train_step(mel, labels, prev, audio=False)
+            if rank == 0 and it % log_every == 0:
+                print(f"step {it} train_loss {loss.item():.4f}", flush=True)
+            it += 1
+        validate(last_ep)
     if rank == 0:
         out_dir = os.path.join(str(cfg.get("output_dir", ".")), f"{cfg.model_type}_{cfg.dataset_type}",
                                "version_0", "checkpoints")

@@ -96,3 +96,28 @@ def test_every_binding_the_host_code_calls_exists():
     missing = sorted(n for n in used if not hasattr(lib, n))
     assert not missing, missing
     assert {"gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "add_rmsnorm_bwd", "embed_bwd", "cross_entropy"} <= used
+
+
+def test_master_version_sees_writes_through_reparented_parameters():
+    """After `.to()` / `_apply` every nn.Parameter owns a version counter of its own: writes by
+    torch.optim or load_state_dict must still invalidate the bf16 shadows."""
+    import torch
+    from mrmt3.synthetic import T5_SMALL
+    from models.t5 import T5ForConditionalGeneration
+    cfg = dict(T5_SMALL, num_layers=1, num_decoder_layers=1)
+    m = T5ForConditionalGeneration(cfg)
+    m._apply(lambda t: t.clone())                       # what .to(device) does, on the CPU
+    v0 = m.flat.master_version()
+    assert m.flat.P._version == m.flat.P._version       # P's own counter is not what moves below
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    p_ver = m.flat.P._version
+    opt.step()
+    assert m.flat.master_version() != v0
+    v1 = m.flat.master_version()
+    other = {k: v + 1 for k, v in m.state_dict().items()}
+    m.load_state_dict(other)
+    assert m.flat.master_version() != v1
+    assert torch.equal(m.flat.master("lm_head.weight"), other["lm_head.weight"])
+    del p_ver

@@ -121,3 +121,29 @@ def test_adamw_state_layout_against_torch_optimizer(variant):
     bad = {"state": {}, "param_groups": [{"params": [0, 1]}]}
     with pytest.raises(ValueError):
         ck.adamw_state_to_flat(bad, f2, order)
+
+
+def test_lightning_checkpoint_lr_matches_what_torch_lambdalr_holds_after_n_steps():
+    """the saved lr / _last_lr must be lambda(N) (what torch's LambdaLR holds after N optimizer steps and
+    the resumed step uses), not the lr of the last executed step; and there is no empty `loops` dict that
+    Lightning's restore_loops() would index with 'fit_loop'."""
+    from types import SimpleNamespace
+    from utils import cosine_warmup_lambda
+    m = _module().load_golden()
+    m.flat.ensure_adam()
+    lam = cosine_warmup_lambda(10, 100, min_lr=1e-4)
+    n = 7
+    params = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.AdamW(params, lr=2e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    for _ in range(n):
+        opt.step()
+        sched.step()
+    fake = SimpleNamespace(lr_dev=torch.tensor([2e-4 * lam(n - 1)]), host_step=n, base_lr=2e-4, lr_lambda=lam,
+                           betas=(0.9, 0.999), eps=1e-8, wd=0.01)
+    blob = ck.lightning_checkpoint(m, fake)
+    assert "loops" not in blob
+    assert blob["optimizer_states"][0]["param_groups"][0]["lr"] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12)
+    assert blob["lr_schedulers"][0]["_last_lr"][0] == pytest.approx(sched.get_last_lr()[0], rel=1e-12)
+    assert blob["lr_schedulers"][0]["last_epoch"] == sched.state_dict()["last_epoch"]
+    assert blob["lr_schedulers"][0]["_step_count"] == sched.state_dict()["_step_count"]

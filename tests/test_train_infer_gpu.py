@@ -193,7 +193,7 @@ defaults:
     (tmp_path / "cfg" / "model" / "MT3Net.yaml").write_text(MODEL % ("mt3_net.MT3Net", ""))
     (tmp_path / "cfg" / "dataset" / "Slakh.yaml").write_text("train:\n  mel_length: ${mel_length}\n")
     out = tmp_path / "out"
-    base = ["--config-dir", str(tmp_path / "cfg"), "--config-name", "config"]
+    base = ["--config-dir", str(tmp_path / "cfg"), "--config-name", "config", "+synthetic=True"]
     train.main(base + ["+max_steps=2", f"+output_dir={out}"])
     ckpt = out / "MT3Net_Slakh" / "version_0" / "checkpoints" / "last.ckpt"
     assert ckpt.exists() and (ckpt.parent / "last.pt").exists()
@@ -203,6 +203,36 @@ defaults:
     assert torch.load(out2 / "MT3Net_Slakh" / "version_0" / "checkpoints" / "last.ckpt", weights_only=False)["global_step"] == 3
     with pytest.raises(ValueError):
         train.main(base + ["+max_steps=1", f"+output_dir={out2}", "path=weights.bin"])
+    # without +synthetic the configured dataset is instantiated (train.py:48-59) ...
+    import sys
+    (tmp_path / "toyset.py").write_text(
+        "import numpy as np, torch\n"
+        "from torch.utils.data import Dataset\n"
+        "class Toy(Dataset):\n"
+        "    def __init__(self, mel_length, n): self.L, self.n = mel_length, n\n"
+        "    def __len__(self): return self.n\n"
+        "    def __getitem__(self, i):\n"
+        "        rs = np.random.RandomState(i)\n"
+        "        return (torch.from_numpy(rs.rand(2, self.L, 512).astype('float32')),\n"
+        "                torch.from_numpy(rs.randint(3, 1000, size=(2, 128)).astype('int64')))\n"
+        "def collate(batch):\n"
+        "    return torch.cat([b[0] for b in batch]), torch.cat([b[1] for b in batch])\n")
+    sys.path.insert(0, str(tmp_path))
+    (tmp_path / "cfg" / "dataset" / "Slakh.yaml").write_text(
+        "train:\n  _target_: toyset.Toy\n  mel_length: ${mel_length}\n  n: 3\n"
+        "val:\n  _target_: toyset.Toy\n  mel_length: ${mel_length}\n  n: 1\n"
+        "collate_fn: toyset.collate\n")
+    (tmp_path / "cfg" / "config.yaml").write_text(top.replace("    batch_size: 1\n", "    batch_size: 1\n  val:\n    batch_size: 1\n"))
+    real = ["--config-dir", str(tmp_path / "cfg"), "--config-name", "config"]
+    out3 = tmp_path / "out3"
+    train.main(real + [f"+output_dir={out3}"])            # one epoch of 3 batches + validation
+    assert torch.load(out3 / "MT3Net_Slakh" / "version_0" / "checkpoints" / "last.ckpt", weights_only=False)["global_step"] == 3
+    # ... and a dataset package that cannot be imported stops the run instead of training on synthetic data
+    (tmp_path / "cfg" / "dataset" / "Slakh.yaml").write_text(
+        "train:\n  _target_: dataset_not_installed.Slakh\nval:\n  _target_: dataset_not_installed.Slakh\n"
+        "collate_fn: dataset_not_installed.collate\n")
+    with pytest.raises(RuntimeError, match="synthetic"):
+        train.main(real + [f"+output_dir={out3}"])
 
 
 def test_rows_from_a_recording_feed_the_trainer(dev):
@@ -325,3 +355,33 @@ def test_full_benchmark_batch_gradient_is_the_mean_of_its_halves(dev):
     assert abs(loss - (la + lb) / 2) < 2e-5
     rel = ((g_all - (g_a + g_b) / 2).norm() / g_all.norm()).item()
     assert rel < 3e-3, rel
+
+
+def test_bf16_shadows_follow_torch_optimizer_and_load_state_dict(dev):
+    """after `.to(device)` torch.optim.AdamW / load_state_dict write through Parameters whose
+    version counters are not P's; the bf16 shadow (and transposed dgrad copy) must still be rebuilt."""
+    from mrmt3.synthetic import synth_mel, synth_labels
+    mel = torch.from_numpy(synth_mel(2)).to(dev)
+    lab = torch.from_numpy(synth_labels(2, 128, full=False, seed=5, mean_len=60)).to(dev)
+    m = _model("t5", dev, dropout_rate=0.0)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    for _ in range(2):
+        out = m(inputs=mel, labels=lab)
+        loss = torch.nn.functional.cross_entropy(out.view(-1, 1536), lab.view(-1), ignore_index=-100)
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+    m.engine.prepare(True)
+    assert torch.equal(m.flat.S, m.flat.P.bfloat16())
+    o, r, c = m.flat.groups["lm_head"]
+    assert torch.equal(m.flat.WT("lm_head"), m.flat.S[o:o + r * c].view(r, c).t().contiguous())
+    # forward, load other weights, forward again: the logits must change
+    m.eval()
+    with torch.no_grad():
+        a = m(inputs=mel, labels=lab).clone()
+        other = {k: (v * 0.5 if v.dim() == 2 else v) for k, v in m.state_dict().items()}
+        m.load_state_dict(other)
+        b = m(inputs=mel, labels=lab)
+    assert (a - b).abs().max().item() > 1e-2
+    assert torch.equal(m.flat.S, m.flat.P.bfloat16())
