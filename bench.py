@@ -211,6 +211,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, not measured: the trainer runs its first steps eagerly and then captures the step into hipGraphs
+    # (mrmt3/trainer.py); make sure that has happened before the W warm-up steps, whatever W is
+    while trainer.use_graph and not trainer.graph_captured:
+        trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
     for _ in range(args.warmup):
         loss = trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
     sync()
@@ -238,6 +242,7 @@ def main():
                    "audio_seconds_per_step": B * world * SEG_SECONDS},
         "final_loss": final_loss,
         "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
+        "step_graph": bool(trainer.use_graph and trainer.graph_captured),
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
         "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
@@ -247,12 +252,14 @@ def main():
         # event-to-event duration includes the time it shares the CUs with the kernel it overlaps.
         # Pass 2 serialises everything on one stream: per-kernel durations in isolation.
         n_rf = max(1, min(args.steps, 3))
+        graph_was, trainer.use_graph = trainer.use_graph, False      # per-launch events need eager launches
         fam = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), n_rf)
         eng = trainer.engine
         was = eng.overlap_wgrad
         eng.overlap_wgrad = False
         fam_iso = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), n_rf)
         eng.overlap_wgrad = was
+        trainer.use_graph = graph_was
     if rank == 0 and not args.no_roofline:
         dom = "gemm_nt_bf16"        # forward + dgrad Linear layers: the family with the most FLOPs per step
 

@@ -89,7 +89,7 @@ int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int 
  * Dropout masks are regenerated from (seed, stream_id, element index); p==0 disables them. */
 int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const float* w, float eps,
                           float* x1, void* xn, int xn_dtype, float* rstd, int rows, int cols,
-                          float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                          float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_y, uint32_t stream_out,
                           int out_drop, void* stream);
 /* backward of the above:
  *   g    = dxn (f32 or bf16, dxn_dtype) [* out-dropout mask]
@@ -109,32 +109,35 @@ int mrmt3_norm_dw_reduce(const void* workspaces, const void* dws, const int* par
 int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int dres_dtype, const float* x1,
                           const float* rstd, const float* w, void* dx1, int dx1_dtype, void* dy_bf16,
                           float* dw, int rows, int cols,
-                          float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                          float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_y, uint32_t stream_out,
                           int out_drop, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K5: attention core (HF T5Attention without relative bias: softmax(q k^T [+causal]) v, scale
  * 1.0, fp32 softmax; models/t5.py:487-490,636-648) -------------------------------------------------
  * q [B][Lq][*] , k/v [B][Lk][*] with head h at columns [h*64, h*64+64) of the row (row strides
  * ldq/ldk/ldv/ldo in elements; batch strides = L*ld).  head_dim is fixed at 64 (d_kv).
- * o [B][Lq][H*64] (ldo), lse [B][H][Lq] f32.  causal!=0 masks key > query.  Attention-probability
+ * o [B][Lq][H*64] (ldo), lse [B][H][Lq] f32.  o_lo (nullable, bf16 kernel only, same layout and stride as o) receives
+ * bf16(O - bf16(O)), the low half of the f32 output: hand it to mrmt3_attn_bwd and delta = rowsum(dO*O) is formed from
+ * O to ~16 bits, which keeps dS = P*(dP - delta) accurate when the value rows share a large common component.
+ * causal!=0 masks key > query.  Attention-probability
  * dropout (p_drop) uses a counter hash of (seed, b, h, q, k).  dtype = MRMT3_BF16 (MFMA flash
  * kernel) or MRMT3_F32 (exact-f32 reference-grade kernel used for parity/decoding). */
 int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
-                   int ldo, float* lse, int B, int H, int Lq, int Lk, int causal, int dtype,
-                   float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+                   int ldo, void* o_lo, float* lse, int B, int H, int Lq, int Lk, int causal, int dtype,
+                   float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 /* backward (bf16 only): delta [B][H][Lq] f32 scratch is written by the call.
  * dq/dk/dv share the layout (and strides) of q/k/v. */
 int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
-                   const void* o, int ldo, const void* d_o, int lddo, const float* lse, float* delta,
+                   const void* o, int ldo, const void* o_lo, const void* d_o, int lddo, const float* lse, float* delta,
                    void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Lq,
-                   int Lk, int causal, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+                   int Lk, int causal, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 
 /* ---- K7: gated-GELU (HF T5DenseGatedGeluDense: gelu_new(h0) * h1, then dropout) ----------------
  * h [rows][2*dff] = [wi_0 x | wi_1 x] -> g [rows][dff] */
 int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop,
-                    uint64_t seed, uint32_t stream_id, void* stream);
+                    uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
-                    uint64_t seed, uint32_t stream_id, void* stream);
+                    uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 
 /* ---- K8: embedding gather + sinusoid add (+dropout) and its scatter-add backward ---------------
  * models/t5.py:539-540,596-601 and `_shift_right` (t5.py:148-150).
@@ -144,21 +147,21 @@ int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, 
  * pos may be NULL (plain gather, used for the segment-memory ids). */
 int mrmt3_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* x, int rows,
                     int seq_len, int d, int vocab, int shift, int start_id, int pad_id,
-                    int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id, void* stream);
+                    int pos_offset, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 /* dtable[id] += dropmask(dx[row]).  No atomics: rows are ranked by id (counting sort), summed in sorted order and
  * every table row has one writer, so the result is bitwise reproducible and insensitive to how skewed the ids are.
  * workspace >= mrmt3_embed_bwd_workspace_bytes(rows, vocab, d); vocab <= 16384. */
 size_t mrmt3_embed_bwd_workspace_bytes(int rows, int vocab, int d);
 int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtable, int rows, int seq_len, int d,
-                    int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed,
+                    int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed, const int32_t* step_dev,
                     uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream);
 /* x[rows][d] f32 = src[rows][d] (src_dtype) + pos[(row % seq_len)+pos_offset], then dropout
  * (the encoder side of models/t5.py:596-601, input = proj(mel)); backward is dropmask only. */
 int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos, float* x, int rows, int seq_len,
-                     int d, int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id,
+                     int d, int pos_offset, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id,
                      void* stream);
 /* out_bf16 = dropmask(dx)  (gradient w.r.t. the GEMM output feeding addpos / any dropout site) */
-int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed,
+int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed, const int32_t* step_dev,
                         uint32_t stream_id, void* stream);
 
 /* ---- K9: cross-entropy over lm_head logits (tasks/mt3_net.py:32-35; weighted variant :96-108) ---

@@ -50,6 +50,7 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
 // in the loop; the constant keep scale is applied once to the accumulated O / dV (and inside the
 // fused multiply-add that forms dS), which takes a multiply per element out of the inner loop.
 struct AttnDrop {
+  const int* step;   // nullable device step counter (see DropCfg::step)
   unsigned seed;
   unsigned thresh8;  // 0 = off
   float scale;
@@ -57,8 +58,9 @@ struct AttnDrop {
 #define DROP_CQ 0x9E3779B1u
 #define DROP_CK 0x85EBCA6Bu
 #define DROP_CB 0xC2B2AE35u
-__host__ inline AttnDrop make_attn_drop(float p, unsigned long long seed, unsigned stream) {
+__host__ inline AttnDrop make_attn_drop(float p, unsigned long long seed, unsigned stream, const int* step) {
   AttnDrop d;
+  d.step = p > 0.f ? step : nullptr;
   d.seed = ((unsigned)seed ^ (unsigned)(seed >> 32)) + stream * 0x27D4EB2Fu;
   if (p <= 0.f) { d.thresh8 = 0; d.scale = 1.f; }
   else {
@@ -95,6 +97,13 @@ __device__ __forceinline__ float rows_max(float v) {
 
 struct AttnParams {
   const bf16_t *q, *k, *v, *o, *d_o;
+  // low half of the f32 attention output, bf16(O - bf16(O)): written by the forward next to `out` when the caller
+  // keeps the tape, read back by the dQ kernel so that delta = rowsum(dO * O) sees O to ~16 bits.  With delta taken
+  // from the bf16-rounded O alone, dP - delta loses the exact cancellation of whatever the value rows have in common
+  // (dS_ij = P_ij dO_i.(V_j - O_i)): q/k weight gradients were 3x further from the fp32 gradient than the
+  // reference's own bf16-autocast run (tests/golden/bf16_bound.npz), the v/o gradients were not.
+  const bf16_t* o_lo_in;
+  bf16_t* o_lo_out;
   bf16_t *out, *dq, *dk, *dv;
   float* lse;
   float* delta;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
-  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  const unsigned drop_bh = P.drop.seed + step_salt(P.drop.step) + (unsigned)(b * P.H + h) * DROP_CB;
   const int n_qt = ceil_div(P.Lq, 128);
   const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk), vres = rows_rsrc(vb, P.Lk, P.ldv);
   const unsigned k_lane = rows8_lane_off(P.ldk, lane), v_lane = rows8_lane_off(P.ldv, lane);
@@ -327,11 +336,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     l += __shfl_xor(l, 32, 64);
     if (qrow[qt] >= P.Lq) continue;
     const float inv = l > 0.f ? P.drop.scale / l : 0.f;    // the dropout keep scale is applied here, once
-    bf16_t* orow = P.out + ((size_t)b * P.Lq + qrow[qt]) * P.ldo + h * HD;
+    const size_t ooff = ((size_t)b * P.Lq + qrow[qt]) * P.ldo + h * HD;
+    bf16_t* orow = P.out + ooff;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 v = oT[qt][dt] * inv;
-      *(u32x2*)(orow + dt * 16 + fg * 4) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      const unsigned h01 = pack_bf2(v[0], v[1]), h23 = pack_bf2(v[2], v[3]);
+      *(u32x2*)(orow + dt * 16 + fg * 4) = u32x2{h01, h23};
+      if (P.o_lo_out) {
+        const float r0 = v[0] - __uint_as_float(h01 << 16), r1 = v[1] - __uint_as_float(h01 & 0xFFFF0000u);
+        const float r2 = v[2] - __uint_as_float(h23 << 16), r3 = v[3] - __uint_as_float(h23 & 0xFFFF0000u);
+        *(u32x2*)(P.o_lo_out + ooff + dt * 16 + fg * 4) = u32x2{pack_bf2(r0, r1), pack_bf2(r2, r3)};
+      }
     }
     if (fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] * LN2 + __logf(l);
   }
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
   const float* lse = P.lse + ((size_t)b * P.H + h) * P.Lq;
   const float* dlt = P.delta + ((size_t)b * P.H + h) * P.Lq;
-  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  const unsigned drop_bh = P.drop.seed + step_salt(P.drop.step) + (unsigned)(b * P.H + h) * DROP_CB;
   const int n_kt = ceil_div(P.Lk, 128);
   const __amdgpu_buffer_rsrc_t qres = rows_rsrc(qb, P.Lq, P.ldq), dores = rows_rsrc(dob, P.Lq, P.lddo);
   const unsigned q_lane = rows8_lane_off(P.ldq, lane), do_lane = rows8_lane_off(P.lddo, lane);
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
-  const unsigned drop_bh = P.drop.seed + (unsigned)(b * P.H + h) * DROP_CB;
+  const unsigned drop_bh = P.drop.seed + step_salt(P.drop.step) + (unsigned)(b * P.H + h) * DROP_CB;
   const int n_qt = ceil_div(P.Lq, 128);
   const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk), vres = rows_rsrc(vb, P.Lk, P.ldv);
   const unsigned k_lane = rows8_lane_off(P.ldk, lane), v_lane = rows8_lane_off(P.ldv, lane);
@@ -557,9 +573,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     float part = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 of = *(const bf16x8*)(P.o + ((size_t)b * P.Lq + r) * P.ldo + h * HD + ks * 32 + fg * 8);
+      const size_t ooff = ((size_t)b * P.Lq + r) * P.ldo + h * HD + ks * 32 + fg * 8;
+      const bf16x8 of = *(const bf16x8*)(P.o + ooff);
 #pragma unroll
       for (int e = 0; e < 8; ++e) part = fmaf(bf2f((bf16_t)dof[qt][ks][e]), bf2f((bf16_t)of[e]), part);
+      if (P.o_lo_in) {
+        const bf16x8 ol = *(const bf16x8*)(P.o_lo_in + ooff);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part = fmaf(bf2f((bf16_t)dof[qt][ks][e]), bf2f((bf16_t)ol[e]), part);
+      }
     }
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
@@ -723,8 +745,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 }
 
 extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
-                              int ldo, float* lse, int B, int H, int Lq, int Lk, int causal, int dtype, float p_drop,
-                              uint64_t seed, uint32_t stream_id, void* stream) {
+                              int ldo, void* o_lo, float* lse, int B, int H, int Lq, int Lk, int causal, int dtype, float p_drop,
+                              uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(q && k && v && o, "attn_fwd: null pointer");
   MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_fwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
@@ -743,9 +765,10 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   AttnParams P;
   memset(&P, 0, sizeof(P));
   P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.out = (bf16_t*)o; P.lse = lse;
+  P.o_lo_out = (bf16_t*)o_lo;
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
-  P.drop = make_attn_drop(p_drop, seed, stream_id);
+  P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
   const dim3 grid(attn_grid_x(Lq, causal), H, B);
   if (causal && P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, P);
   else if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, P);
@@ -756,9 +779,9 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
 }
 
 extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
-                              int ldo, const void* d_o, int lddo, const float* lse, float* delta, void* dq, int lddq,
+                              int ldo, const void* o_lo, const void* d_o, int lddo, const float* lse, float* delta, void* dq, int lddq,
                               void* dk, int lddk, void* dv, int lddv, int B, int H, int Lq, int Lk, int causal,
-                              float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+                              float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_bwd: bad sizes");
   MR_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 &&
@@ -767,10 +790,11 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   memset(&P, 0, sizeof(P));
   P.q = (const bf16_t*)q; P.k = (const bf16_t*)k; P.v = (const bf16_t*)v; P.o = (const bf16_t*)o;
   P.d_o = (const bf16_t*)d_o; P.lse = (float*)lse; P.delta = delta;
+  P.o_lo_in = (const bf16_t*)o_lo;
   P.dq = (bf16_t*)dq; P.dk = (bf16_t*)dk; P.dv = (bf16_t*)dv;
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo; P.lddo = lddo; P.lddq = lddq; P.lddk = lddk; P.lddv = lddv;
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
-  P.drop = make_attn_drop(p_drop, seed, stream_id);
+  P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
   hipStream_t s = (hipStream_t)stream;
   // dQ first: it derives delta = rowsum(dO * O) from operands it loads anyway and leaves it for dK/dV
   const dim3 gq(attn_grid_x(Lq, causal), H, B), gk(attn_grid_x(Lk, causal), H, B);

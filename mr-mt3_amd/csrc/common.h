@@ -82,7 +82,14 @@ struct DropCfg {
   unsigned key;      // seed and site id folded together
   unsigned thresh;   // 16-bit threshold (0 => dropout off)
   float scale;       // 65536 / (65536 - thresh)
+  const int* step;   // nullable DEVICE step counter: salts the key in-kernel, so a replayed hipGraph (whose by-value
+                     // arguments are frozen at capture) still draws new masks every optimizer step
 };
+// salt of the optimizer step read from device memory (0 when there is no counter: masks as before)
+__device__ __forceinline__ unsigned step_salt(const int* step) {
+  return step ? drop_mix((unsigned)(*step) * 0x9E3779B1u + 0x7F4A7C15u) : 0u;
+}
+#define DROP_STEP(d) (d).key += step_salt((d).step)
 // keep-scale for 4 consecutive elements whose first flat index is idx4*4
 __device__ __forceinline__ void drop_mask4(const DropCfg& d, unsigned long long idx4, float m[4]) {
   const unsigned c = ((unsigned)idx4 << 1) ^ ((unsigned)(idx4 >> 31) * 0xC2B2AE35u);
@@ -92,8 +99,9 @@ __device__ __forceinline__ void drop_mask4(const DropCfg& d, unsigned long long 
   m[2] = (h1 & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
   m[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
 }
-__host__ inline DropCfg make_drop(float p, unsigned long long seed, unsigned stream) {
+__host__ inline DropCfg make_drop(float p, unsigned long long seed, unsigned stream, const int* step = nullptr) {
   DropCfg d;
+  d.step = p > 0.f ? step : nullptr;
   d.key = ((unsigned)seed ^ ((unsigned)(seed >> 32) * 0x9E3779B1u)) + stream * 0x85EBCA6Bu;
   if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; }
   else {

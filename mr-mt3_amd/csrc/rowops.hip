@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const float* __res
                                                               float* __restrict__ x1, TN* __restrict__ xn,
                                                               float* __restrict__ rstd_out, int rows, int cols,
                                                               DropCfg dy, DropCfg dout, int out_drop) {
+  DROP_STEP(dy); DROP_STEP(dout);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -90,12 +91,12 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const float* __res
 
 extern "C" int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype, const float* w, float eps,
                                      float* x1, void* xn, int xn_dtype, float* rstd, int rows, int cols,
-                                     float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                                     float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_y, uint32_t stream_out,
                                      int out_drop, void* stream) {
   MR_CHECK_ARG(x0 && w && xn, "add_rmsnorm_fwd: null pointer");
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_fwd: cols must be 256, 512, 1024 or 2048");
-  DropCfg dy = make_drop(p_drop, seed, stream_y), dn = make_drop(p_drop, seed, stream_out);
+  DropCfg dy = make_drop(p_drop, seed, stream_y, step_dev), dn = make_drop(p_drop, seed, stream_out, step_dev);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH2(TY, TN, NV)                                                                                 \
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
                                                               bf16_t* __restrict__ dy, float* __restrict__ dw_part, int rows,
                                                               int cols, DropCfg ddy, DropCfg dout, int out_drop,
                                                               int* __restrict__ dw_counters) {
+  DROP_STEP(ddy); DROP_STEP(dout);
   __shared__ float red[4 * 256 * NV];  // [wave][col]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (dw_counters != nullptr && blockIdx.x == 0 && (int)threadIdx.x < (cols + 63) / 64) dw_counters[threadIdx.x] = 0;
@@ -304,7 +306,7 @@ extern "C" size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols) {
 extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int dres_dtype, const float* x1,
                                      const float* rstd, const float* w, void* dx1, int dx1_dtype, void* dy_bf16,
                                      float* dw, int rows, int cols,
-                                     float p_drop, uint64_t seed, uint32_t stream_y, uint32_t stream_out,
+                                     float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_y, uint32_t stream_out,
                                      int out_drop, void* workspace, size_t workspace_bytes, void* stream) {
   MR_CHECK_ARG(dw == nullptr || workspace, "add_rmsnorm_bwd: dw needs a workspace");
   MR_CHECK_ARG(workspace == nullptr || workspace_bytes >= mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols),
@@ -316,7 +318,7 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
   MR_CHECK_ARG(dxn && x1 && rstd && w && dx1, "add_rmsnorm_bwd: null pointer");
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
-  DropCfg dy = make_drop(p_drop, seed, stream_y), dn = make_drop(p_drop, seed, stream_out);
+  DropCfg dy = make_drop(p_drop, seed, stream_y, step_dev), dn = make_drop(p_drop, seed, stream_out, step_dev);
 #define LAUNCH3(NV, TG, TRI, TRO)                                                                                 \
   hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG, TRI, TRO>), dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0, \
                      (hipStream_t)stream, (const TG*)dxn, (const TRI*)dres, x1, rstd, w, (TRO*)dx1, (bf16_t*)dy_bf16,  \
@@ -380,6 +382,7 @@ __device__ __forceinline__ void gelu_new_fd(float x, float* f, float* d) {
 // Both kernels move 8 elements (two dropout quads) per thread and iteration: 16-byte accesses for bf16.
 template <typename T>
 __global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ g, int rows, int dff, DropCfg d) {
+  DROP_STEP(d);
   const size_t n8 = (size_t)rows * dff / 8;
   const int dff8 = dff / 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -406,6 +409,7 @@ __global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ g, int
 
 __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ dg, bf16_t* __restrict__ dh,
                                  int rows, int dff, DropCfg d) {
+  DROP_STEP(d);
   const size_t n8 = (size_t)rows * dff / 8;
   const int dff8 = dff / 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -444,10 +448,10 @@ static inline int ew_blocks(size_t n_items) {
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
-extern "C" int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop, uint64_t seed,
+extern "C" int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop, uint64_t seed, const int32_t* step_dev,
                                uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(h && g && rows > 0 && dff % 8 == 0, "geglu_fwd: bad args");
-  DropCfg d = make_drop(p_drop, seed, stream_id);
+  DropCfg d = make_drop(p_drop, seed, stream_id, step_dev);
   const int blocks = ew_blocks((size_t)rows * dff / 8);
   if (dtype == MRMT3_BF16)
     hipLaunchKernelGGL(geglu_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
@@ -460,9 +464,9 @@ extern "C" int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dt
 }
 
 extern "C" int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
-                               uint64_t seed, uint32_t stream_id, void* stream) {
+                               uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(h && dg && dh && rows > 0 && dff % 8 == 0, "geglu_bwd: bad args");
-  DropCfg d = make_drop(p_drop, seed, stream_id);
+  DropCfg d = make_drop(p_drop, seed, stream_id, step_dev);
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)h, (const bf16_t*)dg, (bf16_t*)dh, rows, dff, d);
   MR_CHECK_LAUNCH("geglu_bwd");
@@ -491,6 +495,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ pos, float* __restrict__ x, int rows,
                                                         int seq_len, int d, int vocab, int shift, int start_id,
                                                         int pad_id, int pos_offset, DropCfg dc) {
+  DROP_STEP(dc);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -618,6 +623,7 @@ __global__ __launch_bounds__(256) void eb_sum_kernel(const int* __restrict__ ord
                                                       const int* __restrict__ base, const float* __restrict__ dx,
                                                       float* __restrict__ dtable, float* __restrict__ part, int rows,
                                                       int d, DropCfg dc) {
+  DROP_STEP(dc);
   __shared__ int srow[EB_CHUNK], sid[EB_CHUNK];
   const int p0 = blockIdx.x * EB_CHUNK, n = min(EB_CHUNK, rows - p0);
   if (threadIdx.x < n) {
@@ -686,11 +692,11 @@ __global__ __launch_bounds__(128) void eb_combine_kernel(const int* __restrict__
 
 extern "C" int mrmt3_embed_fwd(const int64_t* ids, const float* table, const float* pos, float* x, int rows,
                                int seq_len, int d, int vocab, int shift, int start_id, int pad_id, int pos_offset,
-                               float p_drop, uint64_t seed, uint32_t stream_id, void* stream) {
+                               float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(ids && table && x && rows > 0 && seq_len > 0 && d % 4 == 0, "embed_fwd: bad args");
   hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids,
                      table, pos, x, rows, seq_len, d, vocab, shift, start_id, pad_id, pos_offset,
-                     make_drop(p_drop, seed, stream_id));
+                     make_drop(p_drop, seed, stream_id, step_dev));
   MR_CHECK_LAUNCH("embed_fwd");
   return MRMT3_OK;
 }
@@ -698,7 +704,7 @@ extern "C" int mrmt3_embed_fwd(const int64_t* ids, const float* table, const flo
 extern "C" size_t mrmt3_embed_bwd_workspace_bytes(int rows, int vocab, int d) { return eb_plan(rows, vocab, d).total; }
 
 extern "C" int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtable, int rows, int seq_len, int d,
-                               int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed,
+                               int vocab, int shift, int start_id, int pad_id, float p_drop, uint64_t seed, const int32_t* step_dev,
                                uint32_t stream_id, void* workspace, size_t workspace_bytes, void* stream) {
   MR_CHECK_ARG(ids && dx && dtable && workspace && rows > 0 && seq_len > 0 && d % 4 == 0 && vocab > 0,
                "embed_bwd: bad args");
@@ -718,7 +724,7 @@ extern "C" int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtabl
   hipLaunchKernelGGL(eb_scan_ids_kernel, dim3(1), dim3(1024), 0, s, base, vocab);
   hipLaunchKernelGGL(eb_scatter_kernel, dim3(P.n_wg), dim3(EB_ROWS), 0, s, tok, hist, base, order, rows, vocab);
   hipLaunchKernelGGL(eb_sum_kernel, dim3(P.n_chunk), dim3(256), 0, s, order, tok, base, dx, dtable, part, rows, d,
-                     make_drop(p_drop, seed, stream_id));
+                     make_drop(p_drop, seed, stream_id, step_dev));
   hipLaunchKernelGGL(eb_combine_kernel, dim3(vocab), dim3(128), 0, s, base, part, dtable, d);
   MR_CHECK_LAUNCH("embed_bwd");
   return MRMT3_OK;
@@ -727,6 +733,7 @@ extern "C" int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtabl
 template <typename T>
 __global__ void addpos_fwd_kernel(const T* __restrict__ src, const float* __restrict__ pos, float* __restrict__ x,
                                   size_t n4, int seq_len, int d, int pos_offset, DropCfg dc) {
+  DROP_STEP(dc);
   const int d4 = d / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const size_t row = i / d4;
@@ -747,11 +754,11 @@ __global__ void addpos_fwd_kernel(const T* __restrict__ src, const float* __rest
 }
 
 extern "C" int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos, float* x, int rows, int seq_len,
-                                int d, int pos_offset, float p_drop, uint64_t seed, uint32_t stream_id,
+                                int d, int pos_offset, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id,
                                 void* stream) {
   MR_CHECK_ARG(src && pos && x && rows > 0 && seq_len > 0 && d % 4 == 0, "addpos_fwd: bad args");
   const size_t n4 = (size_t)rows * d / 4;
-  DropCfg dc = make_drop(p_drop, seed, stream_id);
+  DropCfg dc = make_drop(p_drop, seed, stream_id, step_dev);
   if (src_dtype == MRMT3_BF16)
     hipLaunchKernelGGL(addpos_fwd_kernel<bf16_t>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, pos, x, n4, seq_len, d, pos_offset, dc);
@@ -763,6 +770,7 @@ extern "C" int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos
 }
 
 __global__ void dropmask_cast_kernel(const float* __restrict__ dx, bf16_t* __restrict__ out, size_t n4, DropCfg dc) {
+  DROP_STEP(dc);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float a[4];
     load4<float>(dx + i * 4, a);
@@ -776,11 +784,11 @@ __global__ void dropmask_cast_kernel(const float* __restrict__ dx, bf16_t* __res
   }
 }
 
-extern "C" int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed,
+extern "C" int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed, const int32_t* step_dev,
                                    uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(dx && out_bf16 && n % 4 == 0, "dropmask_cast: bad args");
   hipLaunchKernelGGL(dropmask_cast_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dx,
-                     (bf16_t*)out_bf16, n / 4, make_drop(p_drop, seed, stream_id));
+                     (bf16_t*)out_bf16, n / 4, make_drop(p_drop, seed, stream_id, step_dev));
   MR_CHECK_LAUNCH("dropmask_cast");
   return MRMT3_OK;
 }

@@ -101,6 +101,23 @@ class GradBuckets:
     def reset(self):
         self._works, self._fired = [], set()
 
+    @property
+    def active(self) -> bool:
+        """Will firing a bucket enqueue a collective?"""
+        return self.world > 1 or self.force
+
+    def triggered_by(self, prefix, i):
+        """Indices of the buckets that the completion of `prefix` layer i finishes."""
+        return [idx for idx, b in enumerate(self.buckets) if b["trigger"] == (prefix, i)]
+
+    def fire(self, idx):
+        self._fire(idx)
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+
     def _fire(self, idx):
         if idx in self._fired:
             return

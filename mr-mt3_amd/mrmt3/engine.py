@@ -51,6 +51,10 @@ class Engine:
         self._pos = None
         self._stream_ctr = 0
         self.seed = 365
+        # optional DEVICE step counter (int32[1]) salting every dropout mask in-kernel.  The trainer sets it (and
+        # restarts the site counter every step) so that a hipGraph replay, whose by-value arguments are frozen,
+        # still draws fresh masks each step — and draws the SAME masks as the eager path would.
+        self.step_dev = None
         # dtype of sublayer outputs / dgrad outputs entering the fp32 residual add: the compute dtype
         # (bf16 halves that stream's HBM traffic; the residual itself and all statistics stay fp32)
         self.y_dtype = compute_dtype
@@ -62,7 +66,11 @@ class Engine:
         # ends) halves the largest streams of the backward row kernels; the forward residual stays f32
         self.res_grad_dtype = (torch.bfloat16 if compute_dtype == torch.bfloat16 and
                                os.environ.get("MRMT3_RES_GRAD", "bf16") == "bf16" else torch.float32)
+        # lm_head (and the final decoder norm feeding it) in "bf16" (MFMA bf16 operands) or "f32" (exact-f32 MFMA on
+        # the master weights; inference / parity only)
+        self.head_dtype = "bf16"
         self._side = None
+        self._side_dirty = False
         self._held = []
         self.norm_dw = lib.NormDwBatch() if os.environ.get("MRMT3_NORM_DW_BATCH", "1") != "0" else None
 
@@ -103,6 +111,7 @@ class Engine:
         side.wait_event(ev)
         lib.gemm_tn(a, b, out, accumulate=True, stream=side)
         self._held.append((a, b))
+        self._side_dirty = True
 
     def _norm_bwd(self, *a, **kw):
         """lib.add_rmsnorm_bwd with the norm-weight gradient deferred to one batched reduction (flush_norm_dw)."""
@@ -116,7 +125,10 @@ class Engine:
         """Make the current stream wait for every weight gradient issued so far (and sum the queued norm-weight
         gradients: both are what a gradient bucket needs before it is sent)."""
         self.flush_norm_dw()
-        if self.overlap_wgrad and self._side is not None:
+        if self.overlap_wgrad and self._side is not None and self._side_dirty:
+            # (only when the side stream has work since the last join: under graph capture a wait on a stream that
+            # is not part of the capture would tie the graph to uncaptured work)
+            self._side_dirty = False
             torch.cuda.current_stream().wait_stream(self._side)
             # operands may be recycled now: whatever the current stream does next runs after the side work
             self._held.clear()
@@ -128,7 +140,7 @@ class Engine:
             raise RuntimeError("backward is implemented for the bf16 compute path only")
 
     # ---- one T5Stack (models/t5.py:507-702) ----------------------------------------------------------
-    def stack_fwd(self, prefix, x, B, L, n_layers, is_decoder, enc=None, Le=0, p=0.0, tape=None):
+    def stack_fwd(self, prefix, x, B, L, n_layers, is_decoder, enc=None, Le=0, p=0.0, tape=None, out_dtype=None):
         """x: [B*L, d] fp32 (embeddings + sinusoid, dropout already applied).
         enc: [B*Le, d] compute-dtype encoder states for cross-attention.  Returns the final-normed
         (and dropped) states [B*L, d] in the compute dtype."""
@@ -141,45 +153,47 @@ class Engine:
             # -- self attention
             s_in = sy
             x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.0.layer_norm.weight"), eps, dt, write_x1=True,
-                                              p=p, seed=self.seed, stream_y=s_in, x1=None if keep else x)
+                                              p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
             qkv = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.qkv"))
             s_att = self._sid()
-            o, lse = lib.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, L, L,
-                                  is_decoder, p=p, seed=self.seed, stream_id=s_att, want_lse=keep)
+            o, lse, o_lo = lib.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, L, L,
+                                        is_decoder, p=p, seed=self.seed, step=self.step_dev, stream_id=s_att,
+                                        want_lse=keep, want_lo=keep)
             y = lib.gemm_nt(o, self.W(f"{prefix}.{i}.o"), out_dtype=self.y_dtype)
             sy = self._sid()
             if keep:
-                tape.push(kind="self", i=i, x1=x, xn=xn, rstd=rstd, qkv=qkv, o=o, lse=lse, s_in=s_in, s_att=s_att)
+                tape.push(kind="self", i=i, x1=x, xn=xn, rstd=rstd, qkv=qkv, o=o, o_lo=o_lo, lse=lse, s_in=s_in,
+                          s_att=s_att)
             ff = 1
             if is_decoder and enc is not None:
                 s_in = sy
                 x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.1.layer_norm.weight"), eps, dt,
-                                                  p=p, seed=self.seed, stream_y=s_in, x1=None if keep else x)
+                                                  p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
                 q = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.cq"))
                 kv = lib.gemm_nt(enc, self.W(f"{prefix}.{i}.ckv"))
                 s_att = self._sid()
-                o, lse = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, L, Le, False, p=p, seed=self.seed,
-                                      stream_id=s_att, want_lse=keep)
+                o, lse, o_lo = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, L, Le, False, p=p, seed=self.seed,
+                                            step=self.step_dev, stream_id=s_att, want_lse=keep, want_lo=keep)
                 y = lib.gemm_nt(o, self.W(f"{prefix}.{i}.co"), out_dtype=self.y_dtype)
                 sy = self._sid()
                 if keep:
-                    tape.push(kind="cross", i=i, x1=x, xn=xn, rstd=rstd, q=q, kv=kv, o=o, lse=lse, s_in=s_in,
-                              s_att=s_att)
+                    tape.push(kind="cross", i=i, x1=x, xn=xn, rstd=rstd, q=q, kv=kv, o=o, o_lo=o_lo, lse=lse,
+                              s_in=s_in, s_att=s_att)
                 ff = 2
             # -- gated-GELU feed forward
             s_in = sy
             x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.{ff}.layer_norm.weight"), eps, dt,
-                                              p=p, seed=self.seed, stream_y=s_in, x1=None if keep else x)
+                                              p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
             h = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.wi"))
             s_g = self._sid()
-            g = lib.geglu_fwd(h, p=p, seed=self.seed, stream_id=s_g)
+            g = lib.geglu_fwd(h, p=p, seed=self.seed, step=self.step_dev, stream_id=s_g)
             y = lib.gemm_nt(g, self.W(f"{prefix}.{i}.wo"), out_dtype=self.y_dtype)
             sy = self._sid()
             if keep:
                 tape.push(kind="ff", i=i, ff=ff, x1=x, xn=xn, rstd=rstd, h=h, g=g, s_in=s_in, s_g=s_g)
         s_out = self._sid()
-        x, out, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{prefix}.final_layer_norm.weight"), eps, dt, p=p,
-                                           seed=self.seed, stream_y=sy, stream_out=s_out, out_drop=True,
+        x, out, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{prefix}.final_layer_norm.weight"), eps, out_dtype or dt, p=p,
+                                           seed=self.seed, step=self.step_dev, stream_y=sy, stream_out=s_out, out_drop=True,
                                            x1=None if keep else x)
         if keep:
             tape.push(kind="final", x1=x, rstd=rstd, s_in=sy, s_out=s_out, prefix=prefix, n_layers=n_layers,
@@ -199,7 +213,7 @@ class Engine:
         has_y = n_layers > 0
         rg = self.res_grad_dtype if has_y else torch.float32
         dx, dy = self._norm_bwd(d_out, None, fin["x1"], fin["rstd"], self.ln(f"{prefix}.final_layer_norm.weight"),
-                                     f.grad(f"{prefix}.final_layer_norm.weight"), want_dy=has_y, p=p, seed=seed,
+                                     f.grad(f"{prefix}.final_layer_norm.weight"), want_dy=has_y, p=p, seed=seed, step=self.step_dev,
                                      stream_y=fin["s_in"], stream_out=fin["s_out"], out_drop=True, dx1_dtype=rg)
         for i in reversed(range(n_layers)):
             b = f"{prefix}.block.{i}.layer"
@@ -208,11 +222,11 @@ class Engine:
             ff = t["ff"]
             self.wgrad(dy, t["g"], f.GW(f"{prefix}.{i}.wo"))
             dg = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.wo"))
-            dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, stream_id=t["s_g"])
+            dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, step=self.step_dev, stream_id=t["s_g"])
             self.wgrad(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"))
             dxn = lib.gemm_nt(dh, f.WT(f"{prefix}.{i}.wi"), out_dtype=self.y_dtype)
             dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
-                                         f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
+                                         f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
                                          dx1=dx)
             if ff == 2:
                 t = tape.pop()
@@ -223,13 +237,14 @@ class Engine:
                 dkv = torch.empty_like(t["kv"])
                 kv = t["kv"]
                 lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
-                             dkv[:, inner:], B, H, L, Le, False, p=p, seed=seed, stream_id=t["s_att"])
+                             dkv[:, inner:], B, H, L, Le, False, p=p, seed=seed, step=self.step_dev,
+                             stream_id=t["s_att"], o_lo=t["o_lo"])
                 self.wgrad(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"))
                 self.wgrad(dkv, enc, f.GW(f"{prefix}.{i}.ckv"))
                 lib.gemm_nt(dkv, f.WT(f"{prefix}.{i}.ckv"), out=d_enc, accumulate=True)
                 dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
                 dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
-                                             f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, stream_y=t["s_in"],
+                                             f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
                                              dx1=dx)
             t = tape.pop()
             assert t["kind"] == "self" and t["i"] == i
@@ -239,12 +254,12 @@ class Engine:
             dqkv = torch.empty_like(qkv)
             lib.attn_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], t["o"], do, t["lse"],
                          dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, H, L, L, is_dec, p=p,
-                         seed=seed, stream_id=t["s_att"])
+                         seed=seed, step=self.step_dev, stream_id=t["s_att"], o_lo=t["o_lo"])
             self.wgrad(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"))
             dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
             last = i == 0                                     # the stack's input gradient leaves in f32
             dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
-                                         f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed,
+                                         f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed, step=self.step_dev,
                                          stream_y=t["s_in"], dx1=None if (last and dx.dtype != torch.float32) else dx)
             if on_layer_done is not None:
                 on_layer_done(prefix, i)
@@ -266,7 +281,7 @@ class Engine:
         mel2 = self._act(mel.reshape(B * Le, d))
         src = lib.gemm_nt(mel2, self.W("proj"), out_dtype=self.y_dtype)
         s_emb = self._sid()
-        x = lib.addpos_fwd(src, self.pos(mel.device), Le, p=p, seed=self.seed, stream_id=s_emb)
+        x = lib.addpos_fwd(src, self.pos(mel.device), Le, p=p, seed=self.seed, step=self.step_dev, stream_id=s_emb)
         if tape is not None:
             tape.push(kind="enc_in", mel=mel2, s_emb=s_emb, p=p)
         return self.stack_fwd("encoder", x, B, Le, self.cfg["num_layers"], False, p=p, tape=tape)
@@ -275,7 +290,7 @@ class Engine:
         dx = self.stack_bwd(tape, d_enc_out, on_layer_done=on_layer_done)
         t = tape.pop()
         assert t["kind"] == "enc_in"
-        dsrc = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, stream_id=t["s_emb"])
+        dsrc = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, step=self.step_dev, stream_id=t["s_emb"])
         self.wgrad(dsrc, t["mel"], self.flat.GW("proj"))
 
     def segmem(self, ids, B, L, tape=None):
@@ -307,7 +322,8 @@ class Engine:
         xs = x.view(B, L, d)[:, :Ls].contiguous().view(B * Ls, d)
         xns = xn_full.view(B, L, d)[:, :Ls].contiguous().view(B * Ls, d)
         q = lib.gemm_nt(xns, Wqkv[:inner])
-        o, lse = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, Ls, L, False, want_lse=tape is not None)
+        o, lse, o_lo = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, Ls, L, False, want_lse=tape is not None,
+                                    want_lo=tape is not None)
         y = lib.gemm_nt(o, self.W(f"{pre}.0.o"), out_dtype=self.y_dtype)
         x1, xn1, rstd1 = lib.add_rmsnorm_fwd(xs, y, self.ln(f"{b}.1.layer_norm.weight"), eps, dt)
         h = lib.gemm_nt(xn1, self.W(f"{pre}.0.wi"))
@@ -316,7 +332,7 @@ class Engine:
         x2, out, rstd2 = lib.add_rmsnorm_fwd(x1, y2, self.ln(f"{pre}.final_layer_norm.weight"), eps, dt)
         if tape is not None:
             tape.push(kind="seg_in", ids=ids.reshape(-1), emb=emb_a, L=L, short=True, Ls=Ls, B=B, x=x,
-                      xn_full=xn_full, rstd_full=rstd_full, kv=kv, xns=xns, q=q, o=o, lse=lse, x1=x1, xn1=xn1,
+                      xn_full=xn_full, rstd_full=rstd_full, kv=kv, xns=xns, q=q, o=o, o_lo=o_lo, lse=lse, x1=x1, xn1=xn1,
                       rstd1=rstd1, h=h, g=g, x2=x2, rstd2=rstd2)
         return out.view(B, Ls, d)
 
@@ -350,7 +366,7 @@ class Engine:
             kv = t["kv"]
             dq, dkv = torch.empty_like(t["q"]), torch.empty_like(kv)
             lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
-                         dkv[:, inner:], B, H, Ls, L, False)
+                         dkv[:, inner:], B, H, Ls, L, False, o_lo=t["o_lo"])
             self.wgrad(dq, t["xns"], GW[:inner])
             self.wgrad(dkv, t["xn_full"], GW[inner:])
             dxn_full = lib.gemm_nt(dkv, WT[:, inner:], out_dtype=torch.float32)          # [B*L, d]
@@ -421,12 +437,12 @@ class Engine:
             emb = lib.embed_fwd(labels.view(-1), table, None, Ld, shift=True, start_id=start, pad_id=pad)
             xin = torch.cat([mem.float(), emb.view(B, Ld, d)], 1).contiguous()
             Lx = Ld + Ls
-            x = lib.addpos_fwd(xin.view(B * Lx, d), pos, Lx, p=p, seed=self.seed, stream_id=s_emb)
+            x = lib.addpos_fwd(xin.view(B * Lx, d), pos, Lx, p=p, seed=self.seed, step=self.step_dev, stream_id=s_emb)
             enc_cat, Lc = enc, Le
         else:
             Lx = Ld
             x = lib.embed_fwd(labels.view(-1), table, pos, Ld, shift=True, start_id=start, pad_id=pad, p=p,
-                              seed=self.seed, stream_id=s_emb)
+                              seed=self.seed, step=self.step_dev, stream_id=s_emb)
             if mem is not None:
                 enc_cat = torch.cat([enc.view(B, Le, d), mem], 1).contiguous().view(-1, d)
                 Lc = Le + Ls
@@ -435,10 +451,13 @@ class Engine:
         if tape is not None:
             tape.push(kind="dec_in", s_emb=s_emb, p=p, labels=labels, B=B, Le=Le, Ld=Ld, Lx=Lx, Lc=Lc, Ls=Ls,
                       Lm=(ids.shape[1] if variant != "t5" else 0), variant=variant)
-        dec = self.stack_fwd("decoder", x, B, Lx, cfg["num_decoder_layers"], True, enc=enc_cat, Le=Lc, p=p, tape=tape)
+        head_f32 = self.head_dtype == "f32" and tape is None and self.dt == torch.bfloat16
+        dec = self.stack_fwd("decoder", x, B, Lx, cfg["num_decoder_layers"], True, enc=enc_cat, Le=Lc, p=p, tape=tape,
+                             out_dtype=torch.float32 if head_f32 else None)
         if variant == "segmem_v1":
             dec = dec.view(B, Lx, d)[:, Ls:].contiguous().view(B * Ld, d)
-        logits = lib.gemm_nt(dec, self.W("lm_head"), out_dtype=torch.float32)    # [B*Ld, V]
+        w_head = f.W("lm_head", torch.float32) if head_f32 else self.W("lm_head")
+        logits = lib.gemm_nt(dec, w_head, out_dtype=torch.float32)               # [B*Ld, V]
         if tape is not None:
             tape.push(kind="head", dec=dec)
         return logits.view(B, Ld, self.V), tape
@@ -472,14 +491,14 @@ class Engine:
         start, pad = cfg["decoder_start_token_id"], cfg["pad_token_id"]
         d_mem = None
         if variant == "segmem_v1":
-            dxm = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, stream_id=t["s_emb"]).float().view(B, Lx, d)
+            dxm = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, step=self.step_dev, stream_id=t["s_emb"]).float().view(B, Lx, d)
             d_mem = dxm[:, :Ls]
             lib.embed_bwd(t["labels"].view(-1), dxm[:, Ls:].contiguous().view(-1, d), table_g, Ld, shift=True,
                           start_id=start, pad_id=pad)
             d_enc = d_enc_cat
         else:
             lib.embed_bwd(t["labels"].view(-1), dx, table_g, Ld, shift=True, start_id=start, pad_id=pad, p=t["p"],
-                          seed=self.seed, stream_id=t["s_emb"])
+                          seed=self.seed, step=self.step_dev, stream_id=t["s_emb"])
             if variant != "t5":
                 dcat = d_enc_cat.view(B, Lc, d)
                 d_enc = dcat[:, :Le].contiguous().view(-1, d)

@@ -30,21 +30,21 @@ _SIGS = {
     "mrmt3_gemm_nt": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "mrmt3_gemm_tn_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
-    "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp]),
+    "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, vp, cu32, cu32, ci, vp]),
     "mrmt3_add_rmsnorm_bwd_workspace_bytes": (csz, [ci, ci]),
     "mrmt3_add_rmsnorm_bwd_partial_rows": (ci, [ci]),
     "mrmt3_norm_dw_reduce": (ci, [vp, vp, vp, ci, ci, vp]),
-    "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, cf, cu64, cu32, cu32, ci, vp, csz, vp]),
-    "mrmt3_attn_fwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
-    "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
-                            ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
-    "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, cu32, vp]),
-    "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, cu32, vp]),
-    "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp]),
+    "mrmt3_add_rmsnorm_bwd": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, vp, ci, ci, cf, cu64, vp, cu32, cu32, ci, vp, csz, vp]),
+    "mrmt3_attn_fwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
+                            ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_bwd_workspace_bytes": (csz, [ci, ci, ci]),
-    "mrmt3_embed_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, cu64, cu32, vp, csz, vp]),
-    "mrmt3_addpos_fwd": (ci, [vp, ci, vp, vp, ci, ci, ci, ci, cf, cu64, cu32, vp]),
-    "mrmt3_dropmask_cast": (ci, [vp, vp, csz, cf, cu64, cu32, vp]),
+    "mrmt3_embed_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp, csz, vp]),
+    "mrmt3_addpos_fwd": (ci, [vp, ci, vp, vp, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_dropmask_cast": (ci, [vp, vp, csz, cf, cu64, vp, cu32, vp]),
     "mrmt3_ce_count": (ci, [vp, ci, ci, ci, ci, vp, vp]),
     "mrmt3_ce_fwd_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]),
     "mrmt3_adamw_step": (ci, [vp, vp, vp, vp, csz, vp, vp, cf, cf, cf, cf, cf, vp, vp]),
@@ -236,7 +236,7 @@ def gemm_tn(a, b, out, accumulate=False, stream=None):
 
 
 def add_rmsnorm_fwd(x0, y, w, eps, xn_dtype, write_x1=True, p=0.0, seed=0, stream_y=0, stream_out=0,
-                    out_drop=False, x1=None):
+                    out_drop=False, x1=None, step=None):
     _dev(x0, y, w)
     rows, cols = x0.shape
     if x1 is None and write_x1:
@@ -244,8 +244,8 @@ def add_rmsnorm_fwd(x0, y, w, eps, xn_dtype, write_x1=True, p=0.0, seed=0, strea
     xn = torch.empty(rows, cols, device=x0.device, dtype=xn_dtype)
     rstd = torch.empty(rows, device=x0.device, dtype=torch.float32)
     _check(load().mrmt3_add_rmsnorm_fwd(_p(x0), _p(y), _dt(y) if y is not None else F32, _p(w), eps, _p(x1), _p(xn),
-                                        _dt(xn), _p(rstd), rows, cols, p, seed, stream_y, stream_out, int(out_drop),
-                                        _stream()), "add_rmsnorm_fwd")
+                                        _dt(xn), _p(rstd), rows, cols, p, seed, _p(step), stream_y, stream_out,
+                                        int(out_drop), _stream()), "add_rmsnorm_fwd")
     return (x1 if x1 is not None else x0), xn, rstd
 
 
@@ -291,7 +291,7 @@ class NormDwBatch:
 
 
 def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, stream_y=0, stream_out=0,
-                    out_drop=False, dx1=None, dx1_dtype=torch.float32, defer=None):
+                    out_drop=False, dx1=None, dx1_dtype=torch.float32, defer=None, step=None):
     """`dres` and the returned dx1 may be f32 or bf16 (the bf16 engine's residual-gradient stream); `dx1=`
     reuses a buffer (in place when it is `dres` itself).  `defer=` a NormDwBatch: dw is produced by its flush()."""
     _dev(dxn, x1, rstd, w)
@@ -307,84 +307,95 @@ def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, str
         ws = workspace(load().mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols), x1.device)
     _check(load().mrmt3_add_rmsnorm_bwd(_p(dxn), _dt(dxn), _p(dres), _dt(dres) if dres is not None else F32, _p(x1),
                                         _p(rstd), _p(w), _p(dx1), _dt(dx1), _p(dy), _p(dw), rows, cols, p, seed,
-                                        stream_y, stream_out, int(out_drop), _p(ws), ws.numel() if ws is not None else 0,
+                                        _p(step), stream_y, stream_out, int(out_drop), _p(ws), ws.numel() if ws is not None else 0,
                                         _stream()),
            "add_rmsnorm_bwd")
     return dx1, dy
 
 
-def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse=True):
-    """q: [B*Lq, ldq-view], k/v: [B*Lk, ld-view] 2-D views whose column 0 is head 0 / dim 0."""
+def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse=True, step=None, want_lo=None):
+    """q: [B*Lq, ldq-view], k/v: [B*Lk, ld-view] 2-D views whose column 0 is head 0 / dim 0.
+    want_lo (True / False instead of None): returns (o, lse, o_lo) with o_lo = bf16(O - bf16(O)) for the backward's
+    delta when True (and the kernel is the bf16 one), else None."""
     _dev(q, k, v)
     o = torch.empty(B * Lq, H * 64, device=q.device, dtype=q.dtype)
+    o_lo = torch.empty_like(o) if want_lo and q.dtype == torch.bfloat16 else None
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
     # algorithmic FLOPs count the full (unskipped) square, as the reference computes it (SURVEY §8d)
     with _Timed("attn_fwd", 4.0 * B * H * Lq * Lk * 64, "FLOP"):
         _check(load().mrmt3_attn_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-                                     _p(lse), B, H, Lq, Lk, int(causal), _dt(q), p, seed, stream_id, _stream()),
+                                     _p(o_lo), _p(lse), B, H, Lq, Lk, int(causal), _dt(q), p, seed, _p(step), stream_id,
+                                     _stream()),
                "attn_fwd")
+    if want_lo is not None:
+        return o, lse, o_lo
     return o, lse
 
 
-def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0):
-    _dev(q, k, v, o, d_o, lse, dq, dk, dv)
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, step=None, o_lo=None):
+    _dev(q, k, v, o, d_o, lse, dq, dk, dv, o_lo)
+    assert o_lo is None or (o_lo.shape == o.shape and o_lo.stride(0) == o.stride(0))
     delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
     with _Timed("attn_bwd", 8.0 * B * H * Lq * Lk * 64, "FLOP"):
         _check(load().mrmt3_attn_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-                                     _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk),
+                                     _p(o_lo), _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk),
                                      dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, int(causal), p, seed,
-                                     stream_id, _stream()), "attn_bwd")
+                                     _p(step), stream_id, _stream()), "attn_bwd")
     return dq, dk, dv
 
 
-def geglu_fwd(h, p=0.0, seed=0, stream_id=0):
+def geglu_fwd(h, p=0.0, seed=0, stream_id=0, step=None):
     _dev(h)
     rows, two = h.shape
     g = torch.empty(rows, two // 2, device=h.device, dtype=h.dtype)
-    _check(load().mrmt3_geglu_fwd(_p(h), _p(g), rows, two // 2, _dt(h), p, seed, stream_id, _stream()), "geglu_fwd")
+    _check(load().mrmt3_geglu_fwd(_p(h), _p(g), rows, two // 2, _dt(h), p, seed, _p(step), stream_id, _stream()),
+           "geglu_fwd")
     return g
 
 
-def geglu_bwd(h, dg, p=0.0, seed=0, stream_id=0):
+def geglu_bwd(h, dg, p=0.0, seed=0, stream_id=0, step=None):
     _dev(h, dg)
     rows, two = h.shape
     dh = torch.empty_like(h)
-    _check(load().mrmt3_geglu_bwd(_p(h), _p(dg), _p(dh), rows, two // 2, p, seed, stream_id, _stream()), "geglu_bwd")
+    _check(load().mrmt3_geglu_bwd(_p(h), _p(dg), _p(dh), rows, two // 2, p, seed, _p(step), stream_id, _stream()),
+           "geglu_bwd")
     return dh
 
 
-def embed_fwd(ids, table, pos, seq_len, shift, start_id=0, pad_id=0, pos_offset=0, p=0.0, seed=0, stream_id=0):
+def embed_fwd(ids, table, pos, seq_len, shift, start_id=0, pad_id=0, pos_offset=0, p=0.0, seed=0, stream_id=0,
+              step=None):
     _dev(ids, table, pos)
     rows = ids.numel()
     V, d = table.shape
     x = torch.empty(rows, d, device=table.device, dtype=torch.float32)
     _check(load().mrmt3_embed_fwd(_p(ids), _p(table), _p(pos), _p(x), rows, seq_len, d, V, int(shift), start_id,
-                                  pad_id, pos_offset, p, seed, stream_id, _stream()), "embed_fwd")
+                                  pad_id, pos_offset, p, seed, _p(step), stream_id, _stream()), "embed_fwd")
     return x
 
 
-def embed_bwd(ids, dx, dtable, seq_len, shift, start_id=0, pad_id=0, p=0.0, seed=0, stream_id=0):
+def embed_bwd(ids, dx, dtable, seq_len, shift, start_id=0, pad_id=0, p=0.0, seed=0, stream_id=0, step=None):
     _dev(ids, dx, dtable)
     rows = ids.numel()
     V, d = dtable.shape
     ws = workspace(load().mrmt3_embed_bwd_workspace_bytes(rows, V, d), dx.device)
     _check(load().mrmt3_embed_bwd(_p(ids), _p(dx), _p(dtable), rows, seq_len, d, V, int(shift), start_id, pad_id, p,
-                                  seed, stream_id, _p(ws), ws.numel(), _stream()), "embed_bwd")
+                                  seed, _p(step), stream_id, _p(ws), ws.numel(), _stream()), "embed_bwd")
 
 
-def addpos_fwd(src, pos, seq_len, pos_offset=0, p=0.0, seed=0, stream_id=0):
+def addpos_fwd(src, pos, seq_len, pos_offset=0, p=0.0, seed=0, stream_id=0, step=None):
     _dev(src, pos)
     rows, d = src.shape
     x = torch.empty(rows, d, device=src.device, dtype=torch.float32)
     _check(load().mrmt3_addpos_fwd(_p(src), _dt(src), _p(pos), _p(x), rows, seq_len, d, pos_offset, p, seed,
-                                   stream_id, _stream()), "addpos_fwd")
+                                   _p(step), stream_id, _stream()), "addpos_fwd")
     return x
 
 
-def dropmask_cast(dx, p=0.0, seed=0, stream_id=0):
+def dropmask_cast(dx, p=0.0, seed=0, stream_id=0, step=None):
     _dev(dx)
     out = torch.empty(dx.shape, device=dx.device, dtype=torch.bfloat16)
-    _check(load().mrmt3_dropmask_cast(_p(dx), _p(out), dx.numel(), p, seed, stream_id, _stream()), "dropmask_cast")
+    _check(load().mrmt3_dropmask_cast(_p(dx), _p(out), dx.numel(), p, seed, _p(step), stream_id, _stream()),
+           "dropmask_cast")
     return out
 
 

@@ -6,8 +6,22 @@ This is the build's counterpart of what `train.py:43-103` gets from `pl.Trainer.
 optimizer semantics (torch.optim.AdamW defaults, cosine-warmup LambdaLR stepped per batch), one
 process per GPU.  Nothing on the host waits for the device inside a step: the learning rate, the
 step counter and the loss stay in device memory.
+
+Host out of the step.  After two eager steps of a given input shape the whole step — ≈700 kernel launches on two
+streams with their event fork/joins — is captured into hipGraphs and replayed: the host then enqueues a handful of
+graph launches per step instead of ≈600 ctypes calls (19.6 of 28 ms per step in round 1).  What makes the replay equal
+to the eager step bit for bit:
+  * dropout masks are keyed by (seed, site, DEVICE step counter): the site ids restart at 0 every step and the
+    kernels read `step_dev`, which AdamW increments, so frozen by-value arguments still give new masks each step;
+  * the learning rate is written to `lr_dev` (device) before the replay, outside the graph;
+  * inputs are copied into static buffers the captured kernels read.
+With more than one rank the step is cut into one graph per gradient bucket: the RCCL all-reduce of a finished bucket
+is enqueued EAGERLY between two replays on the launch stream, so it still overlaps the rest of backward and no
+collective is ever captured.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -16,9 +30,19 @@ from . import lib
 from .ddp import GradBuckets
 
 
+class _CapturedStep:
+    """One input signature's captured step: graph segments (each followed by the gradient buckets to send), the tail
+    graph (AdamW) and the static tensors the graphs read and write."""
+
+    def __init__(self):
+        self.segments, self.tail = [], None
+        self.inputs = self.labels = self.prev = self.loss = None
+
+
 class Trainer:
     def __init__(self, model, lr: float = 2e-4, lr_lambda=None, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.01, weighted_loss: bool = False, layers_per_bucket: int = 2):
+                 weight_decay: float = 0.01, weighted_loss: bool = False, layers_per_bucket: int = 2,
+                 graph: bool = None):
         self.model, self.flat, self.engine = model, model.flat, model.engine
         assert model.device.type == "cuda", "the trainer drives the HIP kernels: move the model to the GPU first"
         self.base_lr, self.lr_lambda = lr, lr_lambda
@@ -39,19 +63,25 @@ class Trainer:
         if self.world > 1:   # C2: identical replicas
             dist.broadcast(self.flat.P, src=0)
         self.last_loss = None
+        # every dropout mask of a step is salted in-kernel by the device step counter (see module docstring)
+        self.engine.step_dev = self.step_dev
+        self.use_graph = (os.environ.get("MRMT3_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        self.graph_warmup = 2            # eager steps per input signature before capture (tables, workspaces)
+        self._graphs = {}                # signature -> _CapturedStep
+        self._eager_seen = {}
+        self._cap_stream = None
 
     def mel_from_audio(self, audio):
         """[B, n_samples] f32 device audio -> [B, frames, 512] mel in the compute dtype."""
         from contrib import spectrograms as sp
         return sp.logmel_segments(audio, out_bf16=(self.engine.dt == torch.bfloat16))
 
-    def train_step(self, inputs, labels, targets_prev=None, audio: bool = False):
-        """One optimizer step.  `inputs` is mel [B,Le,512] or, with audio=True, raw audio [B,n].
-        Returns the (device, un-synchronised) mean loss of this rank."""
-        m, eng, flat = self.model, self.engine, self.flat
-        m.train()
-        if self.lr_lambda is not None:
-            self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.host_step))
+    # ---- one step's device work (identical in eager mode, under capture and — by replay — afterwards) ------------
+    def _step_body(self, inputs, labels, targets_prev, audio, cut=None):
+        """Enqueues one optimizer step.  `cut(bucket_indices)` is called where a gradient bucket is complete (only
+        when collectives will run); under capture it closes the current graph segment."""
+        eng, flat = self.engine, self.flat
+        eng._stream_ctr = 0                                  # dropout site ids are per-step (step_dev salts them)
         mel = self.mel_from_audio(inputs) if audio else inputs
         logits, tape = eng.forward(mel, labels, targets_prev, training=True, need_grad=True)
         B, Ld, V = logits.shape
@@ -60,9 +90,38 @@ class Trainer:
         del logits
         flat.G.zero_()
         self.buckets.reset()
-        eng.backward(tape, dl, on_layer_done=self.buckets.on_layer_done)
-        self.buckets.finish()
+        if cut is None:
+            eng.backward(tape, dl, on_layer_done=self.buckets.on_layer_done)
+            self.buckets.finish()
+        else:
+            sent = set()
+
+            def layer_done(prefix, i):
+                idx = [j for j in self.buckets.triggered_by(prefix, i) if j not in sent]
+                if idx:
+                    sent.update(idx)
+                    eng.join_wgrad()                         # a capture must end with its forked stream joined
+                    cut(idx)
+            active = self.buckets.active
+            eng.backward(tape, dl, on_layer_done=layer_done if active else None)     # ends with join_wgrad()
+            cut([j for j in range(len(self.buckets.buckets)) if j not in sent] if active else [])
         flat.adamw_step(self.lr_dev, self.step_dev, self.betas, self.eps, self.wd, grad_scale=1.0 / self.world)
+        return loss
+
+    def train_step(self, inputs, labels, targets_prev=None, audio: bool = False):
+        """One optimizer step.  `inputs` is mel [B,Le,512] or, with audio=True, raw audio [B,n].
+        Returns the (device, un-synchronised) mean loss of this rank."""
+        m, eng = self.model, self.engine
+        m.train()
+        if self.lr_lambda is not None:
+            self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.host_step))
+        if targets_prev is not None and eng.variant == "segmem_v2_with_prev":
+            # in place on the caller's tensor, like the reference (t5_segmem_v2_with_prev.py:119)
+            targets_prev.masked_fill_(targets_prev == -100, m.cfg["pad_token_id"])
+        if self.use_graph:
+            loss = self._graph_step(inputs, labels, targets_prev, audio)
+        else:
+            loss = self._step_body(inputs, labels, targets_prev, audio)
         self.host_step += 1
         if self.world > 1:   # C4: logged loss, reduced without blocking the host
             loss = loss.clone()
@@ -70,6 +129,88 @@ class Trainer:
             loss /= self.world
         self.last_loss = loss
         return loss
+
+    # ---- hipGraph capture / replay of the step ---------------------------------------------------------------
+    def _graph_step(self, inputs, labels, targets_prev, audio):
+        sig = (bool(audio), tuple(inputs.shape), inputs.dtype, tuple(labels.shape),
+               None if targets_prev is None else tuple(targets_prev.shape))
+        cap = self._graphs.get(sig)
+        if cap is None:
+            seen = self._eager_seen.get(sig, 0)
+            if seen < self.graph_warmup:
+                self._eager_seen[sig] = seen + 1
+                return self._step_body(inputs, labels, targets_prev, audio)
+            cap = self._capture(sig, inputs, labels, targets_prev, audio)
+        self.engine.prepare(True)          # weights written through torch since the last step? rebuild the shadows
+        cap.inputs.copy_(inputs, non_blocking=True)
+        cap.labels.copy_(labels, non_blocking=True)
+        if cap.prev is not None:
+            cap.prev.copy_(targets_prev, non_blocking=True)
+        self.buckets.reset()
+        for graph, fire in cap.segments:
+            graph.replay()
+            for idx in fire:
+                self.buckets.fire(idx)
+        self.buckets.wait()
+        cap.tail.replay()
+        return cap.loss.clone()            # the graph's own loss scalar is overwritten by the next replay
+
+    def _capture(self, sig, inputs, labels, targets_prev, audio):
+        """Record the step once (nothing executes during capture); `train_step` then replays it, this step included."""
+        eng = self.engine
+        cur = torch.cuda.current_stream()
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream()
+        cs = self._cap_stream
+        eng.prepare(True)
+        cap = _CapturedStep()
+        cap.inputs, cap.labels = inputs.clone(), labels.clone()
+        cap.prev = None if targets_prev is None else targets_prev.clone()
+        cs.wait_stream(cur)
+        pool = None
+        state = {"g": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            if pool is None:
+                g.capture_begin()
+            else:
+                g.capture_begin(pool=pool)
+            state["g"] = g
+
+        def cut(fire):
+            nonlocal pool
+            g = state["g"]
+            g.capture_end()
+            if pool is None:
+                pool = g.pool()
+            cap.segments.append((g, list(fire)))
+            begin()
+
+        overlap_was = eng.overlap_wgrad
+        if os.environ.get("MRMT3_GRAPH_LINEAR", "1") == "1":
+            eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
+        with torch.cuda.stream(cs):
+            begin()
+            try:
+                cap.loss = self._step_body(cap.inputs, cap.labels, cap.prev, audio, cut=cut)
+                state["g"].capture_end()
+            except Exception:
+                try:
+                    state["g"].capture_end()
+                except Exception:
+                    pass
+                raise
+            finally:
+                eng.overlap_wgrad = overlap_was
+            cap.tail = state["g"]
+        cur.wait_stream(cs)
+        self._graphs[sig] = cap
+        return cap
+
+    @property
+    def graph_captured(self) -> bool:
+        return bool(self._graphs)
 
     # ---- checkpoint / resume (Lightning `.ckpt` layout, see mrmt3.checkpoint) -------------------------------
     def save_checkpoint(self, path: str, epoch: int = 0):

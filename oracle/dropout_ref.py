@@ -26,10 +26,19 @@ def drop_mix(x):
     return x
 
 
-def make_drop(p, seed, stream):
-    """-> (key, thresh16, scale) exactly as make_drop() in common.h."""
+def step_salt(step):
+    """common.h step_salt(): what the kernels add to the key when a device step counter is attached (None -> 0)."""
+    if step is None:
+        return 0
+    x = np.array([(int(step) * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF], dtype=np.uint64)
+    return int(drop_mix(x)[0])
+
+
+def make_drop(p, seed, stream, step=None):
+    """-> (key, thresh16, scale) exactly as make_drop() in common.h (+ the in-kernel DROP_STEP salt)."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     key = ((seed & 0xFFFFFFFF) ^ (((seed >> 32) * 0x9E3779B1) & 0xFFFFFFFF)) + (int(stream) * 0x85EBCA6B)
+    key = (key + (step_salt(step) if p > 0.0 else 0)) & 0xFFFFFFFF
     key &= 0xFFFFFFFF
     if p <= 0.0:
         return key, 0, 1.0
@@ -38,10 +47,10 @@ def make_drop(p, seed, stream):
     return key, t, np.float32(65536.0) / (np.float32(65536.0) - np.float32(t))
 
 
-def keep_mask(n, p, seed, stream):
+def keep_mask(n, p, seed, stream, step=None):
     """Boolean keep mask of the first n elements (n % 4 == 0) of a flat tensor, and the keep scale."""
     assert n % 4 == 0
-    key, thresh, scale = make_drop(p, seed, stream)
+    key, thresh, scale = make_drop(p, seed, stream, step)
     if thresh == 0:
         return np.ones(n, dtype=bool), 1.0
     idx4 = np.arange(n // 4, dtype=np.uint64)
@@ -62,12 +71,12 @@ def _attn_mix24(x):
     return x
 
 
-def attn_keep_mask(B, H, Lq, Lk, p, seed, stream):
+def attn_keep_mask(B, H, Lq, Lk, p, seed, stream, step=None):
     """-> (keep[B, H, Lq, Lk] bool, scale).  Element (q, k) of head-matrix (b, h) belongs to the 2x2 group
     (q >> 1, k >> 1); one mix per group, byte ((q & 1) << 1 | (k & 1)) decides the element; keep iff byte >= thresh8
     with thresh8 = round(256 p) and scale = 256 / (256 - thresh8)."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    s32 = (((seed & 0xFFFFFFFF) ^ (seed >> 32)) + int(stream) * 0x27D4EB2F) & 0xFFFFFFFF
+    s32 = (((seed & 0xFFFFFFFF) ^ (seed >> 32)) + int(stream) * 0x27D4EB2F + step_salt(step)) & 0xFFFFFFFF
     if p <= 0.0:
         return np.ones((B, H, Lq, Lk), dtype=bool), 1.0
     t8 = min(int(float(p) * 256.0 + 0.5), 255)

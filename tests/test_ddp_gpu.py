@@ -39,7 +39,7 @@ def _model(dev):
     return T5ForConditionalGeneration(dict(T5_SMALL, dropout_rate=0.0)).load_golden().to(dev)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, steps=1, graph=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "mr-mt3_amd")):
@@ -55,27 +55,49 @@ def _worker(rank, world, port, q):
         if rank == 1:
             with torch.no_grad():
                 m.flat.P.mul_(1.5)                       # the trainer's initial broadcast must undo this
-        tr = Trainer(m, lr=1e-3)
+        tr = Trainer(m, lr=1e-3, graph=graph)
         audio, lab = _batch(rank)
-        loss = tr.train_step(audio.to(dev), lab.to(dev), audio=True)
+        for _ in range(steps):
+            loss = tr.train_step(audio.to(dev), lab.to(dev), audio=True)
         torch.cuda.synchronize()
+        assert tr.graph_captured == (graph and steps > 2)
+        if tr.graph_captured:       # one graph per gradient bucket, the collectives stay eager between the replays
+            cap = next(iter(tr._graphs.values()))
+            assert len(cap.segments) == len(tr.buckets.buckets) >= 4
         q.put((rank, m.flat.G.cpu().numpy(), m.flat.P.cpu().numpy(), float(loss.item())))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_one_process_on_the_global_batch():
-    assert torch.cuda.is_available()
+def _run_two_ranks(steps=1, graph=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, steps, graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    return res
+
+
+def test_two_ranks_segmented_graph_replay_equals_eager():
+    """World 2: the step is captured as one hipGraph per gradient bucket with the (gloo here, RCCL on the node)
+    all-reduces enqueued eagerly between the replays.  Five steps (2 eager, capture, 2 replays) land on the same
+    bits as five eager steps, on both ranks."""
+    assert torch.cuda.is_available()
+    eager = _run_two_ranks(steps=5, graph=False)
+    graph = _run_two_ranks(steps=5, graph=True)
+    for (r0, g0, p0, l0), (r1, g1, p1, l1) in zip(eager, graph):
+        assert r0 == r1 and np.array_equal(g0, g1) and np.array_equal(p0, p1) and abs(l0 - l1) < 2e-6
+    assert np.array_equal(graph[0][2], graph[1][2])
+
+
+def test_two_ranks_match_one_process_on_the_global_batch():
+    assert torch.cuda.is_available()
+    res = _run_two_ranks()
     (_, g0, p0, l0), (_, g1, p1, l1) = res
     assert np.array_equal(g0, g1) and np.array_equal(p0, p1)       # identical replicas after the step
     assert abs(l0 - l1) < 1e-6                                      # the logged loss is the all-reduced mean
@@ -83,7 +105,7 @@ def test_two_ranks_match_one_process_on_the_global_batch():
     from mrmt3.trainer import Trainer
     dev = torch.device("cuda", 0)
     m = _model(dev)
-    tr = Trainer(m, lr=1e-3)
+    tr = Trainer(m, lr=1e-3, graph=False)
     a0, t0 = _batch(0)
     a1, t1 = _batch(1)
     loss = tr.train_step(torch.cat([a0, a1]).to(dev), torch.cat([t0, t1]).to(dev), audio=True)

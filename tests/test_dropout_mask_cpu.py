@@ -39,3 +39,22 @@ def test_sites_and_seeds_are_independent_and_p_zero_keeps_everything():
     for p in (0.05, 0.3, 0.5):
         k, s = dr.keep_mask(n, p, 99, 2)
         assert abs(k.mean() - (1 - p)) < 3e-3 and abs(k.mean() * s - 1.0) < 4e-3
+
+
+def test_step_salt_gives_independent_masks_per_step():
+    """The in-kernel step salt (device step counter, hipGraph replays): consecutive steps draw independent masks with
+    the same keep rate; no counter attached = the unsalted mask."""
+    n = 1 << 20
+    base, _ = dr.keep_mask(n, 0.1, 365, 9)
+    same, _ = dr.keep_mask(n, 0.1, 365, 9, step=None)
+    assert (base == same).all()
+    masks = [dr.keep_mask(n, 0.1, 365, 9, step=s)[0] for s in (0, 1, 2, 3, 64500)]
+    for i, a in enumerate(masks):
+        assert abs(a.mean() - 0.9) < 2e-3
+        assert (a != base).mean() > 0.15
+        af = a - a.mean()
+        for b in masks[i + 1:]:
+            assert abs((af * (b - b.mean())).mean() / af.var()) < 5e-3
+    ka, _ = dr.attn_keep_mask(1, 2, 128, 128, 0.1, 365, 4, step=5)
+    kb, _ = dr.attn_keep_mask(1, 2, 128, 128, 0.1, 365, 4, step=6)
+    assert abs(ka.mean() - (1 - 26 / 256)) < 1e-2 and (ka != kb).mean() > 0.12

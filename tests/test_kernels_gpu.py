@@ -287,6 +287,18 @@ def test_dropout_mask_equals_the_restatement_bit_for_bit(dev, p, seed, stream):
     keep, scale = dr.keep_mask(rows * cols, p, seed, stream)
     assert ((out != 0) == keep).all()
     assert abs(float(out[keep][0]) - scale) < 8e-3 * scale        # bf16 output
+    # with a DEVICE step counter attached the kernel salts the key itself (hipGraph replays: by-value arguments are
+    # frozen, the counter is not): every step a new mask, each equal to the restatement
+    step = torch.zeros(1, device=dev, dtype=torch.int32)
+    seen = [keep]
+    for n in (0, 1, 2, 1000003):
+        step.fill_(n)
+        out = lib.dropmask_cast(torch.ones(rows, cols, device=dev), p=p, seed=seed, stream_id=stream,
+                                step=step).float().cpu().numpy().reshape(-1)
+        keep_n, _ = dr.keep_mask(rows * cols, p, seed, stream, step=n)
+        assert ((out != 0) == keep_n).all()
+        assert all((keep_n != k).mean() > 0.1 for k in seen)     # 2 p (1 - p) >= 0.18 for independent masks
+        seen.append(keep_n)
 
 
 def test_dropout_sites_consistent(dev):
@@ -440,6 +452,16 @@ def test_attn_dropout_mask_equals_the_restatement(dev, B, H, Lq, causal):
     dv_want = want.sum(2)                                                      # [B, H, Lk]: sum_q Pd[q, k]
     dv_got = dv.float().view(B, Lk, H, 64)[..., 0].permute(0, 2, 1).cpu().numpy()
     assert abs(dv_got - dv_want).max() < 2e-2 * max(1.0, dv_want.max())
+    # device step counter: forward and backward both follow it
+    step = torch.full((1,), 41, device=dev, dtype=torch.int32)
+    o2, lse2 = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=p, seed=seed, stream_id=stream, step=step)
+    keep2, _ = dr.attn_keep_mask(B, H, Lq, Lk, p, seed, stream, step=41)
+    got2 = o2.float().view(B, Lq, H, 64).permute(0, 2, 1, 3).cpu().numpy()
+    assert ((got2 != 0) == (keep2 & visible)).all() and (keep2 != keep).mean() > 0.1
+    lib.attn_bwd(q, k, v, o2, d_o, lse2, dq, dk, dv, B, H, Lq, Lk, causal, p=p, seed=seed, stream_id=stream, step=step)
+    dv_want2 = ((keep2 & visible) * (scale / n_vis)).sum(2)
+    dv_got2 = dv.float().view(B, Lk, H, 64)[..., 0].permute(0, 2, 1).cpu().numpy()
+    assert abs(dv_got2 - dv_want2).max() < 2e-2 * max(1.0, dv_want2.max())
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 6, 256, 256, False), (1, 6, 128, 128, True), (1, 6, 100, 320, False)])
@@ -620,3 +642,40 @@ def test_errors_are_reported_not_fatal(dev):
         lib.gemm_nt(a, a)
     with pytest.raises(RuntimeError, match="device tensors"):
         lib.gemm_nt(torch.zeros(128, 64).bfloat16(), torch.zeros(128, 64).bfloat16())
+
+
+def test_attn_bwd_delta_from_hi_lo_output_keeps_the_common_mode_cancellation(dev):
+    """Value rows with a large common component (V_j = vbar + small): dS_ij = P_ij dO_i.(V_j - O_i) cancels vbar
+    exactly only if delta = dO.O sees O beyond bf16.  With the forward's low half (o_lo) handed to the backward the
+    dq / dk error against an f64 reference drops by several times; without it the old behaviour remains."""
+    from mrmt3 import lib
+    torch.manual_seed(0)
+    B, H, Lq, Lk = 2, 6, 256, 256
+    q = (torch.randn(B * Lq, H * 64, device=dev) * 0.3).bfloat16()
+    k = (torch.randn(B * Lk, H * 64, device=dev) * 0.3).bfloat16()
+    v = (torch.randn(1, H * 64, device=dev) + 0.1 * torch.randn(B * Lk, H * 64, device=dev)).bfloat16()
+    d_o = (torch.randn(B * Lq, H * 64, device=dev) * 1e-2).bfloat16()
+    o, lse, o_lo = lib.attn_fwd(q, k, v, B, H, Lq, Lk, False, want_lo=True)
+    o2, _ = lib.attn_fwd(q, k, v, B, H, Lq, Lk, False)
+    assert torch.equal(o, o2) and o_lo is not None
+
+    def heads(t, L):
+        return t.double().view(B, L, H, 64).permute(0, 2, 1, 3)
+    qd, kd, vd, dod = heads(q, Lq), heads(k, Lk), heads(v, Lk), heads(d_o, Lq)
+    P = torch.softmax(qd @ kd.transpose(-1, -2), -1)
+    O = P @ vd
+    # the low half is the rounding residual of the high half (|lo| <= half an ulp of hi) and moves the sum towards O
+    assert (o_lo.float().abs() <= o.float().abs() * 2.0 ** -8 + 1e-30).all()
+    assert (heads(o, Lq) + heads(o_lo, Lq) - O).norm() < 0.7 * (heads(o, Lq) - O).norm()
+    dP = dod @ vd.transpose(-1, -2)
+    dS = P * (dP - (P * dP).sum(-1, keepdim=True))
+    dq_ref, dk_ref = dS @ kd, dS.transpose(-1, -2) @ qd
+    err = {}
+    for name, lo in (("hi_only", None), ("hi_lo", o_lo)):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, False, o_lo=lo)
+        err[name] = (((heads(dq, Lq) - dq_ref).norm() / dq_ref.norm()).item(),
+                     ((heads(dk, Lk) - dk_ref).norm() / dk_ref.norm()).item())
+    print("attention backward, common-mode V: rel err (dq, dk)", err)
+    assert err["hi_lo"][0] < 6e-3 and err["hi_lo"][1] < 6e-3
+    assert err["hi_only"][0] > 2.5 * err["hi_lo"][0] and err["hi_only"][1] > 2.5 * err["hi_lo"][1]

@@ -3,9 +3,18 @@ itself and (b) the CPU oracle on identical seeded inputs.
 
 Tolerances (stated per test):
   fp32 compute path : logits within 2e-4 of the reference, loss within 2e-5, greedy token ids bit-exact
-  bf16 compute path : loss within 1e-3 (north_star), logits rel-L2 < 1.5e-2, argmax agreement > 97 %
-  bf16 gradients    : per-tensor cosine > 0.995 and rel-L2 < 8e-2 vs fp32 autograd of the oracle
+  bf16 compute path : loss within 1e-3 (north_star).  Logits: north_star's 1e-3 is not reachable by ANY bf16-operand
+                      arithmetic on this model — the reference itself, run under torch.autocast(bfloat16), deviates from
+                      its own fp32 logits by max|d| 3.6e-2..4.8e-2, rel-L2 7.3e-3..8.0e-3 (tests/golden/bf16_bound.npz,
+                      recorded by make_golden.py --bf16-bound).  The HIP path is held to THAT, per variant: max|d| and
+                      rel-L2 no worse than the reference's autocast run, absolute cap 4e-2 (measured 2.3e-2..2.9e-2;
+                      lm_head in exact f32 changes nothing, profiles/tools/bf16_logit_gap.py: the deviation is the
+                      accumulated operand rounding of 16 layers)
+  bf16 gradients    : per tensor, rel-L2 vs the fp32 oracle gradient <= 1.5 x what the reference's autocast gradient
+                      loses on that tensor (+2e-3), < 2.5e-2 absolute, cosine > 0.9995
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -70,7 +79,13 @@ def test_bf16_logits_and_loss(dev, golden, variant):
     loss = torch.nn.functional.cross_entropy(logits.view(-1, 1536).double(), lab_pad.view(-1), ignore_index=-100).item()
     print(variant, "bf16: rel-L2 %.3e max|d| %.3e dloss %.2e" % (rel, np.abs(got - ref).max(), loss - float(golden[f"{variant}.pad.loss"])))
     assert abs(loss - float(golden[f"{variant}.pad.loss"])) < 1e-3       # north_star tolerance on the loss
-    assert rel < 1.5e-2
+    # logits: no worse than what the reference's own bf16-autocast run loses on the same inputs (see module docstring)
+    bound = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bound.npz"))
+    assert rel <= float(bound[f"{variant}.pad.autocast_rel_l2"])
+    max_d = float(np.abs(got - ref).max())
+    assert max_d <= float(bound[f"{variant}.pad.autocast_max_abs"]) and max_d < 4e-2
+    # the sampled logits of the autocast run: the HIP path is also closer to fp32 than autocast is, sample by sample on average
+    assert np.abs(got - ref).mean() <= np.abs(bound[f"{variant}.pad.autocast_logit_val"] - ref).mean()
     assert (logits.argmax(-1).cpu().numpy() == golden[f"{variant}.pad.argmax"]).mean() > 0.97    # near-tied logits flip under bf16
 
 
@@ -113,6 +128,8 @@ def test_bf16_gradients_vs_oracle_autograd(dev, variant):
     loss = torch.nn.functional.cross_entropy(out.view(-1, 1536), lab.to(dev).view(-1), ignore_index=-100)
     loss.backward()
     assert abs(loss.item() - ref_loss.item()) < 2e-3
+    bound = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bound.npz"))
+    ref_rel = dict(zip(bound[f"{variant}.grad_names"].tolist(), bound[f"{variant}.grad_rel_l2"].tolist()))
     worst = (1.0, 0.0, "")
     for k, ref in sd.items():
         g = m.flat.grad(k).cpu()
@@ -124,7 +141,9 @@ def test_bf16_gradients_vs_oracle_autograd(dev, variant):
         rel = ((g - r).norm() / r.norm()).item()
         if cos < worst[0]:
             worst = (cos, rel, k)
-        assert cos > 0.995 and rel < 8e-2, (k, cos, rel)
+        assert cos > 0.9995 and rel < 2.5e-2, (k, cos, rel)
+        if k in ref_rel:        # what the reference's own bf16-autocast gradient loses on this tensor
+            assert rel <= 1.5 * ref_rel[k] + 2e-3, (k, rel, ref_rel[k])
     print(variant, "worst grad tensor:", worst)
     # every parameter exposes its slice of the flat buffer as .grad
     p = dict(m.named_parameters())["lm_head.weight"]

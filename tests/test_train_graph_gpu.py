@@ -1,0 +1,126 @@
+"""The training step replayed from hipGraphs (mrmt3/trainer.py) against the same step launched eagerly.
+
+VERDICT r1 "next round" item 1: the host leaves the step (≈600 ctypes launches -> a handful of graph launches), the
+loss trajectory stays bit-identical to the eager path (no float atomics feed gradients), dropout masks still change
+from step to step under replay (device-side step counter), the learning-rate schedule still applies."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(variant, dev, **cfg_over):
+    from mrmt3.synthetic import T5_SMALL
+    cfg = dict(T5_SMALL, **cfg_over)
+    if variant == "t5":
+        from models.t5 import T5ForConditionalGeneration
+        return T5ForConditionalGeneration(cfg).load_golden().to(dev)
+    from models.t5_segmem_v2_with_prev import T5SegMemV2WithPrev
+    return T5SegMemV2WithPrev(cfg, 1, 64).load_golden().to(dev)
+
+
+def _batches(dev, n, B=3, L=192, with_prev=False):
+    from mrmt3.synthetic import synth_audio, synth_labels
+    out = []
+    for s in range(n):
+        a = torch.from_numpy(synth_audio(B, seed=100 + s)).to(dev)
+        t = torch.from_numpy(synth_labels(B, L, full=False, seed=200 + s, mean_len=90)).to(dev)
+        p = torch.from_numpy(synth_labels(B, L, full=False, seed=300 + s, mean_len=90)).to(dev) if with_prev else None
+        out.append((a, t, p))
+    return out
+
+
+@pytest.mark.parametrize("variant", ["t5", "with_prev"])
+def test_graph_replay_is_bitwise_the_eager_trajectory(dev, variant):
+    """20 optimizer steps, dropout ON, cosine-warmup schedule, three rotating batches: graph trainer == eager trainer
+    in every logged loss and in the final weights and AdamW moments, bit for bit."""
+    from mrmt3.trainer import Trainer
+    from utils import cosine_warmup_lambda
+    lam = cosine_warmup_lambda(5, 100, min_lr=1e-4)
+    data = _batches(dev, 3, with_prev=(variant != "t5"))
+    runs = {}
+    for use_graph in (False, True):
+        m = _model(variant, dev)
+        tr = Trainer(m, lr=1e-3, lr_lambda=lam, graph=use_graph)
+        losses = []
+        for i in range(20):
+            a, t, p = data[i % 3]
+            losses.append(tr.train_step(a, t, None if p is None else p.clone(), audio=True))
+        torch.cuda.synchronize()
+        assert tr.graph_captured == use_graph
+        assert int(tr.step_dev.item()) == 20
+        runs[use_graph] = ([float(x.item()) for x in losses], m.flat.P.clone(), m.flat.M.clone(), m.flat.V.clone())
+    le, lg = runs[False][0], runs[True][0]
+    # (the logged loss scalar is the one float-atomically accumulated value of a step: last-bit differences between
+    # any two runs, eager or not; nothing is computed from it)
+    assert np.allclose(le, lg, rtol=0, atol=2e-6), list(zip(le, lg))
+    assert le[-1] < le[0]                                     # and it is a real training run
+    for a, b in zip(runs[False][1:], runs[True][1:]):
+        assert torch.equal(a, b)
+
+
+def test_masks_change_from_step_to_step_under_replay(dev):
+    """lr = 0 freezes the weights, the batch is the same every step: the loss then varies ONLY through the dropout
+    masks.  Under replay the by-value kernel arguments are frozen, so this is the check that the device step counter
+    reaches the kernels; the values equal the eager trainer's."""
+    from mrmt3.trainer import Trainer
+    a, t, _ = _batches(dev, 1)[0]
+    got = {}
+    for use_graph in (False, True):
+        tr = Trainer(_model("t5", dev), lr=0.0, graph=use_graph)
+        got[use_graph] = [float(tr.train_step(a, t, audio=True).item()) for _ in range(7)]
+    assert np.allclose(got[True], got[False], rtol=0, atol=2e-6)
+    replayed = got[True][2:]                                   # steps 0-1 are the eager warm-up, 2.. come from the graph
+    assert min(abs(x - y) for i, x in enumerate(replayed) for y in replayed[i + 1:]) > 1e-4, replayed
+    # dropout off: every step identical (the only other source of variation would be a bug)
+    tr = Trainer(_model("t5", dev, dropout_rate=0.0), lr=0.0, graph=True)
+    same = [float(tr.train_step(a, t, audio=True).item()) for _ in range(5)]
+    assert max(same) - min(same) < 2e-6, same
+
+
+def test_graph_follows_new_inputs_weights_and_shapes(dev):
+    """Replays read the CURRENT batch (static input buffers are refilled), see weights loaded through torch between
+    steps (shadow refresh outside the graph), and a new input shape gets its own capture."""
+    from mrmt3.trainer import Trainer
+    data = _batches(dev, 4)
+    m = _model("t5", dev, dropout_rate=0.0)
+    tr = Trainer(m, lr=0.0, graph=True)
+    base = [float(tr.train_step(a, t, audio=True).item()) for a, t, _ in data]          # 2 eager + capture + replay
+    again = [float(tr.train_step(a, t, audio=True).item()) for a, t, _ in data]         # all replays
+    assert np.allclose(base, again, rtol=0, atol=2e-6) and min(abs(x - y) for i, x in enumerate(base) for y in base[i + 1:]) > 1e-4
+    sd = {k: (v * 0.5 if v.dim() == 2 else v.clone()) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    changed = float(tr.train_step(*data[0][:2], audio=True).item())
+    assert abs(changed - base[0]) > 1e-3
+    a, t, _ = _batches(dev, 1, B=2, L=128)[0]
+    l1 = [float(tr.train_step(a, t, audio=True).item()) for _ in range(4)]
+    assert len(tr._graphs) == 2 and max(l1) - min(l1) < 2e-6
+
+
+def test_host_issue_time_of_a_replayed_step(dev):
+    """The point of the exercise: enqueueing a replayed step costs the host a small fraction of the eager step."""
+    from mrmt3.trainer import Trainer
+    a, t, _ = _batches(dev, 1, B=8, L=256)[0]
+    times = {}
+    for use_graph in (False, True):
+        tr = Trainer(_model("t5", dev), lr=1e-4, graph=use_graph)
+        for _ in range(4):
+            tr.train_step(a, t, audio=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            tr.train_step(a, t, audio=True)
+        times[use_graph] = (time.perf_counter() - t0) / 10
+        torch.cuda.synchronize()
+    print("host issue per step: eager %.2f ms, graph %.2f ms" % (1e3 * times[False], 1e3 * times[True]))
+    assert times[True] < 3e-3, times
+    assert times[True] < 0.4 * times[False], times
