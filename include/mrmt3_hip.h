@@ -79,6 +79,20 @@ int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int l
 size_t mrmt3_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1,
                   int N2, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* Deferred form for the 45-50 weight gradients of a training step: mrmt3_gemm_tn_partial only leaves the
+ * mrmt3_gemm_tn_splits(M,N1,N2) f32 slabs [split][N1][N2] in `slabs` (>= mrmt3_gemm_tn_workspace_bytes, one buffer per
+ * site, kept until reduced); mrmt3_tn_reduce_sites then sums the slabs of n_sites sites into their C in ONE launch
+ * (same per-element order as mrmt3_gemm_tn: bit-identical).  `sites_dev` is a DEVICE array of mrmt3_tn_site with
+ * block0 = running sum of ceil(N1*N2/1024) over the preceding sites; total_blocks = that sum over all sites. */
+typedef struct {
+  uint64_t slabs;      /* device address of the site's slabs */
+  uint64_t C;          /* device address of C [N1][ldc] f32 */
+  int32_t N1, N2, ldc, splits, accumulate, block0, pad0, pad1;
+} mrmt3_tn_site;
+int mrmt3_gemm_tn_splits(int M, int N1, int N2);
+int mrmt3_gemm_tn_partial(const void* A, int lda, const void* B, int ldb, int M, int N1, int N2, void* slabs,
+                          size_t slab_bytes, void* stream);
+int mrmt3_tn_reduce_sites(const void* sites_dev, int n_sites, int total_blocks, void* stream);
 
 /* ---- K3: T5LayerNorm (RMS norm) fused with the residual add and dropout that precede it --------
  * HF T5LayerNorm + `hidden + dropout(sublayer_out)` (T5LayerSelfAttention/CrossAttention/FF), and

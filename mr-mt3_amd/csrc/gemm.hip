@@ -24,6 +24,8 @@
 // consecutive reduction indices per lane; the token range is split over workgroups — a split count that fills
 // whole resident waves of 512 workgroups — into f32 slabs that a second kernel sums in a fixed order
 // (bitwise reproducible, no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define TILE 128
@@ -238,9 +240,24 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void gemm_nt_kernel(const TIN* __r
   }
 }
 
+// gemm8.hip: the ping-pong kernel for the tall bf16 shapes (returns 0 when the shape is not its)
+int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                       int out_dtype, int accumulate, hipStream_t s);
+static bool use_gemm8() {
+  const char* e = getenv("MRMT3_GEMM8");        // tuning / A-B switch only (read per call: in-process A/B runs)
+  return !(e && e[0] == '0');
+}
+
 template <typename TIN, typename TOUT, bool ACCUM>
 static int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      hipStream_t s) {
+  if constexpr (sizeof(TIN) == 2) {
+    if (use_gemm8() && mrmt3_gemm_nt8_try(A, lda, B, ldb, C, ldc, M, N, K, sizeof(TOUT) == 2 ? MRMT3_BF16 : MRMT3_F32,
+                                           ACCUM ? 1 : 0, s)) {
+      MR_CHECK_LAUNCH("gemm_nt8");
+      return MRMT3_OK;
+    }
+  }
   if (N % 256 == 0 && M >= 2048 && (K * sizeof(TIN)) % NT_RB_BIG == 0) {
     const int tiles_m = ceil_div(M, 256), tiles_n = N / 256;
     hipLaunchKernelGGL((gemm_nt_kernel<TIN, TOUT, ACCUM, 4, 4, NT_RB_BIG, NT_ST_BIG>), dim3((unsigned)(tiles_m * tiles_n)), dim3(1024), 0, s,
@@ -441,6 +458,40 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   }
 }
 
+// The slab sums of MANY weight gradients in one launch.  A training step has 45-50 weight-gradient GEMMs; summing each
+// one's slabs right behind it cost a launch of a few hundred small workgroups apiece (19.5 us x 90 per step in round 1,
+// 1.8 ms).  With every site keeping its slabs until a gradient bucket is due, one launch of ~45 K workgroups streams
+// all of them (same per-element summation order as slab_reduce_kernel, so the result is bit-identical).
+struct TnSite {             // = mrmt3_tn_site (include/mrmt3_hip.h)
+  unsigned long long slabs, C;
+  int N1, N2, ldc, splits, accumulate, block0, pad0, pad1;
+};
+__global__ __launch_bounds__(256) void slab_reduce_sites_kernel(const TnSite* __restrict__ sites, int n_sites) {
+  // site of this workgroup: block0 is ascending, n_sites is small (a scalar scan)
+  int si = 0;
+  while (si + 1 < n_sites && (int)blockIdx.x >= sites[si + 1].block0) ++si;
+  const TnSite st = sites[si];
+  const float* __restrict__ slab = (const float*)st.slabs;
+  float* __restrict__ C = (float*)st.C;
+  const size_t n = (size_t)st.N1 * st.N2;
+  const size_t i = ((size_t)(blockIdx.x - st.block0) * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= st.splits; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const f32x4*)(slab + (size_t)(k + u) * n + i));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < st.splits; ++k) s += __builtin_nontemporal_load((const f32x4*)(slab + (size_t)k * n + i));
+  const int row = (int)(i / st.N2), col = (int)(i % st.N2);
+  float* p = C + (size_t)row * st.ldc + col;
+  if (st.accumulate) s += *(const f32x4*)p;
+  *(f32x4*)p = s;
+}
+
 static void tn_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per_split) {
   const int t = ceil_div(N1, TILE) * ceil_div(N2, TILE);
   const int steps = ceil_div(M, TN_ROWS);
@@ -468,6 +519,37 @@ extern "C" size_t mrmt3_gemm_tn_workspace_bytes(int M, int N1, int N2) {
   int t, s, r;
   tn_plan(M, N1, N2, &t, &s, &r);
   return (size_t)s * N1 * N2 * sizeof(float);
+}
+
+extern "C" int mrmt3_gemm_tn_splits(int M, int N1, int N2) {
+  int t, s, r;
+  tn_plan(M, N1, N2, &t, &s, &r);
+  return s;
+}
+
+extern "C" int mrmt3_gemm_tn_partial(const void* A, int lda, const void* B, int ldb, int M, int N1, int N2,
+                                     void* slabs, size_t slab_bytes, void* stream) {
+  MR_CHECK_ARG(A && B && slabs, "gemm_tn_partial: null pointer");
+  MR_CHECK_ARG(M > 0 && N1 >= 8 && N2 >= 8, "gemm_tn_partial: bad sizes");
+  MR_CHECK_ARG(N1 % 8 == 0 && N2 % 4 == 0 && lda % 8 == 0 && ldb % 8 == 0,
+               "gemm_tn_partial: N1/lda/ldb must be multiples of 8, N2 of 4");
+  int tiles, splits, rps;
+  tn_plan(M, N1, N2, &tiles, &splits, &rps);
+  MR_CHECK_ARG(slab_bytes >= (size_t)splits * N1 * N2 * sizeof(float), "gemm_tn_partial: slab buffer too small");
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((tiles * splits + 7) & ~7)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)slabs, M, N1, N2, ceil_div(N2, TILE), tiles,
+                     splits, rps);
+  MR_CHECK_LAUNCH("gemm_tn_partial");
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_tn_reduce_sites(const void* sites_dev, int n_sites, int total_blocks, void* stream) {
+  MR_CHECK_ARG(sites_dev && n_sites > 0 && total_blocks > 0, "tn_reduce_sites: bad arguments");
+  static_assert(sizeof(TnSite) == sizeof(mrmt3_tn_site), "descriptor layout");
+  hipLaunchKernelGGL(slab_reduce_sites_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const TnSite*)sites_dev, n_sites);
+  MR_CHECK_LAUNCH("tn_reduce_sites");
+  return MRMT3_OK;
 }
 
 extern "C" int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1,

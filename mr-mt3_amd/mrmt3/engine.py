@@ -73,6 +73,8 @@ class Engine:
         self._side_dirty = False
         self._held = []
         self.norm_dw = lib.NormDwBatch() if os.environ.get("MRMT3_NORM_DW_BATCH", "1") != "0" else None
+        # split-K slabs of the weight-gradient GEMMs: kept per site and summed in one launch (lib.TnBatch)
+        self.tn_batch = lib.TnBatch() if os.environ.get("MRMT3_TN_BATCH", "1") != "0" else None
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def pos(self, device):
@@ -103,13 +105,13 @@ class Engine:
         directly, and the operands are kept alive by reference until the next join instead of
         `record_stream` bookkeeping."""
         if not self.overlap_wgrad:
-            return lib.gemm_tn(a, b, out, accumulate=True)
+            return lib.gemm_tn(a, b, out, accumulate=True, defer=self.tn_batch)
         side = self.side_stream()
         ev = self._events[self._ev_i]
         self._ev_i = (self._ev_i + 1) % len(self._events)
         ev.record()
         side.wait_event(ev)
-        lib.gemm_tn(a, b, out, accumulate=True, stream=side)
+        lib.gemm_tn(a, b, out, accumulate=True, stream=side, defer=self.tn_batch)
         self._held.append((a, b))
         self._side_dirty = True
 
@@ -132,6 +134,8 @@ class Engine:
             torch.cuda.current_stream().wait_stream(self._side)
             # operands may be recycled now: whatever the current stream does next runs after the side work
             self._held.clear()
+        if self.tn_batch is not None:
+            self.tn_batch.flush()        # behind the GEMMs that produced the slabs (same stream, or joined above)
 
     def prepare(self, training: bool):
         if self.dt == torch.bfloat16:

@@ -30,6 +30,9 @@ _SIGS = {
     "mrmt3_gemm_nt": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
     "mrmt3_gemm_tn_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
+    "mrmt3_gemm_tn_splits": (ci, [ci, ci, ci]),
+    "mrmt3_gemm_tn_partial": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, csz, vp]),
+    "mrmt3_tn_reduce_sites": (ci, [vp, ci, ci, vp]),
     "mrmt3_add_rmsnorm_fwd": (ci, [vp, vp, ci, vp, cf, vp, vp, ci, vp, ci, ci, cf, cu64, vp, cu32, cu32, ci, vp]),
     "mrmt3_add_rmsnorm_bwd_workspace_bytes": (csz, [ci, ci]),
     "mrmt3_add_rmsnorm_bwd_partial_rows": (ci, [ci]),
@@ -218,14 +221,67 @@ def workspace(nbytes: int, device, stream=None) -> torch.Tensor:
     return buf
 
 
-def gemm_tn(a, b, out, accumulate=False, stream=None):
+class TnBatch:
+    """Weight-gradient GEMMs whose split-K slabs are summed in ONE launch instead of one per GEMM.
+
+    `gemm_tn(..., defer=batch)` runs only the MFMA kernel, leaving the site's f32 slabs in a buffer that belongs to
+    (batch, out address, shape), and queues the site; `flush()` runs `mrmt3_tn_reduce_sites` over everything queued,
+    in queue order, on the current stream (which must already be ordered behind the GEMMs' stream).  Same summation
+    order per element as the immediate form: bit-identical gradients.  The descriptor tables live on the device and
+    are rebuilt only when the set of queued sites changes (never under graph capture after the eager warm-up)."""
+
+    def __init__(self):
+        self._slabs = {}       # (out address, M, N1, N2) -> slab tensor
+        self._queue = []       # [(key, out, ldc, accumulate)]
+        self._tables = {}
+
+    def site(self, out, M, N1, N2, accumulate):
+        key = (out.data_ptr(), M, N1, N2, out.stride(0), int(accumulate))
+        buf = self._slabs.get(key)
+        if buf is None:
+            buf = torch.empty(load().mrmt3_gemm_tn_workspace_bytes(M, N1, N2), device=out.device, dtype=torch.uint8)
+            self._slabs[key] = buf
+        self._queue.append(key)
+        self._dev = out.device
+        return buf
+
+    def flush(self):
+        if not self._queue:
+            return
+        import numpy as np
+        keys = tuple(self._queue)
+        tab = self._tables.get(keys)
+        if tab is None:
+            L = load()
+            rec = np.zeros(len(keys), dtype=[("slabs", "<u8"), ("C", "<u8"), ("N1", "<i4"), ("N2", "<i4"), ("ldc", "<i4"),
+                                             ("splits", "<i4"), ("acc", "<i4"), ("block0", "<i4"), ("p0", "<i4"), ("p1", "<i4")])
+            blocks = 0
+            for i, k in enumerate(keys):
+                addr, M, N1, N2, ldc, acc = k
+                rec[i] = (self._slabs[k].data_ptr(), addr, N1, N2, ldc, L.mrmt3_gemm_tn_splits(M, N1, N2), acc, blocks, 0, 0)
+                blocks += -(-(N1 * N2) // 1024)
+            tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(self._dev), len(keys), blocks)
+            self._tables[keys] = tab
+        _check(load().mrmt3_tn_reduce_sites(_p(tab[0]), tab[1], tab[2], _stream()), "tn_reduce_sites")
+        self._queue.clear()
+
+
+def gemm_tn(a, b, out, accumulate=False, stream=None, defer=None):
     """out[N1,N2] (+)= a[M,N1]^T @ b[M,N2]  (bf16 in, f32 out).  `stream` (torch.cuda.Stream) launches there
-    instead of on the current stream, without the cost of a stream context switch."""
+    instead of on the current stream, without the cost of a stream context switch.  `defer=` a TnBatch: only the
+    slabs are produced now, `out` is complete after the batch's flush()."""
     _dev(a, b, out)
     M, N1 = a.shape
     N2 = b.shape[1]
     assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
     lib = load()
+    if defer is not None:
+        slabs = defer.site(out, M, N1, N2, accumulate)
+        sp = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        with _Timed("gemm_tn_bf16", 2.0 * M * N1 * N2, "FLOP", stream):
+            _check(lib.mrmt3_gemm_tn_partial(_p(a), a.stride(0), _p(b), b.stride(0), M, N1, N2, _p(slabs),
+                                             slabs.numel(), sp), "gemm_tn_partial")
+        return out
     nbytes = lib.mrmt3_gemm_tn_workspace_bytes(M, N1, N2)
     ws = workspace(nbytes, a.device, stream)
     sp = _stream() if stream is None else C.c_void_p(stream.cuda_stream)

@@ -23,7 +23,7 @@ def run():
     loss.backward()
     err = (logits.detach().cpu() - ref).abs().max().item()
     gnorm = model.flat.G.norm().item()
-    assert abs(loss.item() - ref_loss) < 1e-2 and err < 5e-2 and np.isfinite(gnorm) and gnorm > 0, (loss.item(), ref_loss, err, gnorm)
+    assert abs(loss.item() - ref_loss) < 2e-3 and err < 5e-2 and np.isfinite(gnorm) and gnorm > 0, (loss.item(), ref_loss, err, gnorm)
     print("smoke: bf16 fwd+bwd loss %.5f (oracle %.5f) max|dlogit| %.3e |grad| %.3e" % (loss.item(), ref_loss, err, gnorm))
     m32 = T5ForConditionalGeneration(T5_SMALL, compute_dtype=torch.float32).load_golden().to(dev).eval()
     ids = m32.generate(mel.to(dev), max_length=16).cpu()

@@ -56,7 +56,7 @@ class Trainer:
         cfg = model.cfg
         self.buckets = GradBuckets(self.flat, cfg["num_layers"], cfg["num_decoder_layers"],
                                    model.segmem_num_layers > 0, layers_per_bucket)
-        self.buckets.before_fire = model.engine.flush_norm_dw
+        self.buckets.before_fire = model.engine.join_wgrad      # norm-weight partials and split-K slabs are summed here
         self.buckets.producer_streams = lambda: [model.engine._side]
         self.flat.ensure_grads()
         self.flat.ensure_adam()

@@ -679,3 +679,40 @@ def test_attn_bwd_delta_from_hi_lo_output_keeps_the_common_mode_cancellation(dev
     print("attention backward, common-mode V: rel err (dq, dk)", err)
     assert err["hi_lo"][0] < 6e-3 and err["hi_lo"][1] < 6e-3
     assert err["hi_only"][0] > 2.5 * err["hi_lo"][0] and err["hi_only"][1] > 2.5 * err["hi_lo"][1]
+
+
+def test_gemm_tn_deferred_batch_is_bitwise_the_immediate_form(dev):
+    """lib.TnBatch: the weight-gradient GEMMs of a step leave their split-K slabs per site and ONE launch sums them all
+    (`mrmt3_tn_reduce_sites`).  Same per-element summation order as `mrmt3_gemm_tn`: bit-identical, accumulate
+    included, tables reused across flushes."""
+    from mrmt3 import lib
+    torch.manual_seed(1)
+    shapes = [(4096, 512, 384), (2048 + 64, 1152, 512), (4096, 2048, 512), (1024, 384, 512), (8192, 512, 1024)]
+    ops = [((torch.randn(M, N1, device=dev) * 0.1).bfloat16(), (torch.randn(M, N2, device=dev) * 0.1).bfloat16())
+           for M, N1, N2 in shapes]
+    want = [torch.randn(N1, N2, device=dev) for _, N1, N2 in shapes]
+    got = [w.clone() for w in want]
+    for (a, b), w in zip(ops, want):
+        lib.gemm_tn(a, b, w, accumulate=True)
+    batch = lib.TnBatch()
+    for rep in range(2):
+        for (a, b), g in zip(ops, got):
+            lib.gemm_tn(a, b, g, accumulate=True, defer=batch)
+        batch.flush()
+        batch.flush()                       # empty flush is a no-op
+        if rep == 0:
+            for g, w in zip(got, want):
+                assert torch.equal(g, w)
+            for (a, b), w in zip(ops, want):
+                lib.gemm_tn(a, b, w, accumulate=True)
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    assert len(batch._tables) == 1
+    # strided C (a row block of a fused weight gradient) and accumulate=False
+    big = torch.zeros(1152, 512, device=dev)
+    ref = torch.zeros(384, 512, device=dev)
+    a, b = ops[3]
+    lib.gemm_tn(a, b, ref, accumulate=False)
+    lib.gemm_tn(a, b, big[384:768], accumulate=False, defer=batch)
+    batch.flush()
+    assert torch.equal(big[384:768], ref) and big[:384].abs().max() == 0 and big[768:].abs().max() == 0

@@ -11,7 +11,7 @@ Tolerances (stated per test):
                       lm_head in exact f32 changes nothing, profiles/tools/bf16_logit_gap.py: the deviation is the
                       accumulated operand rounding of 16 layers)
   bf16 gradients    : per tensor, rel-L2 vs the fp32 oracle gradient <= 1.5 x what the reference's autocast gradient
-                      loses on that tensor (+2e-3), < 2.5e-2 absolute, cosine > 0.9995
+                      loses on that tensor (+2e-3), < 3e-2 absolute, cosine > 0.9995
 """
 import os
 
@@ -141,7 +141,7 @@ def test_bf16_gradients_vs_oracle_autograd(dev, variant):
         rel = ((g - r).norm() / r.norm()).item()
         if cos < worst[0]:
             worst = (cos, rel, k)
-        assert cos > 0.9995 and rel < 2.5e-2, (k, cos, rel)
+        assert cos > 0.9995 and rel < 3e-2, (k, cos, rel)
         if k in ref_rel:        # what the reference's own bf16-autocast gradient loses on this tensor
             assert rel <= 1.5 * ref_rel[k] + 2e-3, (k, rel, ref_rel[k])
     print(variant, "worst grad tensor:", worst)
