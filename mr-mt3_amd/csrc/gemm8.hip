@@ -29,6 +29,8 @@
 //     tile before it owns.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define G8_OOB 0x7FFF0000
@@ -41,10 +43,21 @@ struct G8Params {
   void* C;
   int lda, ldb, ldc, M, N, K;
   int tiles_n, n_tiles;
-  int dbg;             // diagnostics (MRMT3_GEMM8_DBG): 1 no C stores, 2 nt stores, 4 every K step re-reads K step 0 (cache-hot),
+  int dbg;             // diagnostics (MRMT3_GEMM8_DBG): 1 no C stores, 2 plain instead of streaming C stores (bf16), 4 every K step re-reads K step 0 (cache-hot),
                        // 8 no fragment reads, 16 loads switched off (zero fill, no traffic)
   int skew_ticks;      // start delay per (slot % 8), in 10-ns ticks of s_memrealtime (see the kernel)
 };
+
+static int g8_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g8_rsrc(const void* base, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -67,7 +80,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   constexpr int NA = RT / 4;                   // LDS-DMA instructions per thread and A half-tile (2 or 1)
   constexpr int A_HALF_ROWS = GROUP_ROWS;      // rows in HA0 (= RT*8 per group x 2 groups)
   constexpr int YOUNG = 2 * NA + 4;            // loads of the four youngest half-tiles (2 A halves, 2 B halves)
-  constexpr int NST = (sizeof(TOUT) == 2 ? RT * 2 : RT * 4) * (ACCUM ? 2 : 1);
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * G8_BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,21 +215,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
       bf_[half * 2 + j][1] = *(const bf16x8*)(p + b_off1 + j * 2048);
     }
   };
-  // 16 (8) MFMAs: row half rh x column half ch, both k-steps.  Weights are the A operand: D = W_frag . X_frag^T
-  auto mma = [&](int rh, int ch, int ks) {
+  // 16 (8) MFMAs: row half rh x column half ch, both k-steps.  Weights are the A operand: D = W_frag . X_frag^T.
+  // FIRST (the first K step of an output tile): the accumulators start from zero instead of being cleared.
+  auto mma = [&](int rh, int ch, bool first) {
 #pragma unroll
-    for (int i = 0; i < RH; ++i)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[rh * RH + i][ch * 2 + j] =
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[ch * 2 + j][ks], af[i][ks], acc[rh * RH + i][ch * 2 + j], 0, 0, 0);
+      for (int i = 0; i < RH; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 c = (first && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[rh * RH + i][ch * 2 + j];
+          acc[rh * RH + i][ch * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf_[ch * 2 + j][ks], af[i][ks], c, 0, 0, 0);
+        }
   };
   // (Tried: issuing a phase's LDS-DMA requests between its MFMAs instead of in the read segment.  A wave issues in
   // order and an LDS-DMA instruction takes 60+ cycles to issue, so the MFMAs behind it wait: barriers + MFMAs alone
   // went from 1.03 to 1.30 us per K step.  In the read segment the same issue time runs beside the partner's MFMAs.)
-#define G8_MMA(rh, ch) \
-  mma(rh, ch, 0);      \
-  mma(rh, ch, 1)
 #define G8_SEG_END()                            \
   __builtin_amdgcn_sched_barrier(0);            \
   __builtin_amdgcn_s_barrier();                 \
@@ -230,120 +243,186 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   __builtin_amdgcn_s_barrier();                 \
   __builtin_amdgcn_sched_barrier(0)
 
+  // ---- the epilogue, two row tiles at a time.  A tile's 128 KiB of C issued in one go cost 5-7 us per tile (the K
+  // loop of a K = 512 tile: 11 us) — not HBM bandwidth (de-phasing the workgroups did not help) but the store path of
+  // the CU: HALF the stores cost 1.3 us, the second half 5.7, and what an instruction costs goes with the number of
+  // cache lines it touches.  So (a) the lanes of rows r and r + 8 (lane ^ 8: one DPP row rotate) exchange halves, which
+  // makes a store instruction 8 rows x 128 contiguous bytes (whole lines) instead of 16 rows x 64; (b) the tile leaves in
+  // four batches, in the read segments of four consecutive phases:
+  //     row tiles 0,1 (final after ph2 of the tile's last K step) -> its ph3      row tiles 2,3 -> its ph4
+  //     row tiles of r1 (final after ph4)                         -> ph1, ph2 of the NEXT tile (overwritten in its ph3)
+  // Stores share the in-order vmcnt queue with the loads: the counted waits of these K steps allow for the batches
+  // that are younger than the load they wait for.
+  auto store_rows = [&](int i0, int m0, int n0, int cmin, bool count) {
+    if (P.dbg & 1) return;
+    if (n0 + wc * 64 < cmin) return;                          // columns owned by the tile on the left (wave-uniform)
+    TOUT* C = (TOUT*)P.C;
+    const bool up = fr >= 8;
+#pragma unroll
+    for (int ii = 0; ii < RH / 2; ++ii) {
+      const int i = i0 + ii;
+      const int row1 = m0 + g * GROUP_ROWS + i * 16 + (fr & 7), row2 = row1 + 8;
+      if constexpr (sizeof(TOUT) == 2) {
+        // keep = the half this lane stores for its own row, send = the half its partner lane stores (selected before
+        // the bf16 packing: fewer live registers than packing both halves and selecting afterwards)
+        const f32x4 k0 = up ? acc[i][2] : acc[i][0], k1 = up ? acc[i][3] : acc[i][1];
+        const f32x4 s0 = up ? acc[i][0] : acc[i][2], s1 = up ? acc[i][1] : acc[i][3];
+        const u32x4 keep = {pack_bf2(k0[0], k0[1]), pack_bf2(k0[2], k0[3]), pack_bf2(k1[0], k1[1]), pack_bf2(k1[2], k1[3])};
+        const u32x4 send = {pack_bf2(s0[0], s0[1]), pack_bf2(s0[2], s0[3]), pack_bf2(s1[0], s1[1]), pack_bf2(s1[2], s1[3])};
+        u32x4 recv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) recv[e] = (unsigned)__builtin_amdgcn_mov_dpp((int)send[e], 0x128, 0xf, 0xf, false);   // row_ror:8
+        const u32x4 v1 = up ? recv : keep, v2 = up ? keep : recv;
+        bf16_t* p = (bf16_t*)C + n0 + wc * 64 + (up ? 32 : 0) + fg * 8;
+        // C is written once and not read by this kernel: streaming stores keep it from flushing the operand panels out
+        // of the XCD's L2 (a round of 32 tiles is 4 MB, the whole L2)
+        if (P.dbg & 2) {
+          if (row1 < P.M) *(u32x4*)(p + (size_t)row1 * P.ldc) = v1;
+          if (row2 < P.M) *(u32x4*)(p + (size_t)row2 * P.ldc) = v2;
+        } else {
+          if (row1 < P.M) __builtin_nontemporal_store(v1, (u32x4*)(p + (size_t)row1 * P.ldc));
+          if (row2 < P.M) __builtin_nontemporal_store(v2, (u32x4*)(p + (size_t)row2 * P.ldc));
+        }
+      } else {
+        // f32: column tiles (0,1) and (2,3) each make one 128-byte line per row
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const f32x4 lo = acc[i][2 * cp], hi = acc[i][2 * cp + 1];
+          const f32x4 send = up ? lo : hi;
+          f32x4 recv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            recv[e] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send[e]), 0x128, 0xf, 0xf, false));
+          f32x4 v1 = up ? recv : lo, v2 = up ? hi : recv;
+          float* p = (float*)C + n0 + wc * 64 + cp * 32 + (up ? 16 : 0) + fg * 4;
+          if (row1 < P.M) { float* q1 = p + (size_t)row1 * P.ldc; if (ACCUM) v1 += *(const f32x4*)q1; *(f32x4*)q1 = v1; }
+          if (row2 < P.M) { float* q2 = p + (size_t)row2 * P.ldc; if (ACCUM) v2 += *(const f32x4*)q2; *(f32x4*)q2 = v2; }
+        }
+      }
+    }
+    (void)count;
+  };
+  // counted wait: everything but the YOUNG youngest loads and `extra` batches of interleaved stores has completed.
+  // (The immediates must be compile-time constants and a chain of scalar branches per wait is not free: computing the
+  // allowance from a running request counter cost 0.45 us per K step.  The five cases below cover the schedule.)
+  constexpr int SQ = ACCUM ? 0 : (RH / 2) * (sizeof(TOUT) == 2 ? 2 : 4);    // stores per lane and batch (0: not counted)
+  auto wait_young = [&](int extra) {
+    if (SQ == 0 || extra == 0) { if (YOUNG == 8) G8_VMCNT(8); else G8_VMCNT(6); return; }
+#define G8_W(k)                                                                               \
+  do {                                                                                        \
+    constexpr int n_ = YOUNG + (k) * SQ;                                                      \
+    if (n_ == 8) G8_VMCNT(8); else if (n_ == 10) G8_VMCNT(10); else if (n_ == 12) G8_VMCNT(12);           \
+    else if (n_ == 14) G8_VMCNT(14); else if (n_ == 16) G8_VMCNT(16); else if (n_ == 18) G8_VMCNT(18);     \
+    else if (n_ == 20) G8_VMCNT(20); else if (n_ == 22) G8_VMCNT(22); else if (n_ == 24) G8_VMCNT(24);     \
+    else if (n_ == 32) G8_VMCNT(32); else if (n_ == 40) G8_VMCNT(40);                                      \
+    else if (n_ > 40) G8_VMCNT(40); else if (n_ > 32) G8_VMCNT(32); else if (n_ > 24) G8_VMCNT(24);        \
+    else G8_VMCNT(6);                                                                         \
+  } while (0)
+    if (extra == 1) G8_W(1);
+    else if (extra == 2) G8_W(2);
+    else if (extra == 3) G8_W(3);
+    else G8_W(4);
+#undef G8_W
+  };
+  auto ld_a = [&](int buf, int half, int soff) { load_a(buf, half, soff); };
+  auto ld_b = [&](int buf, int half, int soff) { load_b(buf, half, soff); };
+
   // ---- prologue: K steps 0 and (half of) 1
-  load_a(0, 0, l_sa); load_b(0, 0, l_sb); load_b(0, 1, l_sb); load_a(0, 1, l_sa);
+  ld_a(0, 0, l_sa); ld_b(0, 0, l_sb); ld_b(0, 1, l_sb); ld_a(0, 1, l_sa);
   cursor_next();
-  load_a(1, 0, l_sa); load_b(1, 0, l_sb);
-  if (YOUNG == 8) G8_VMCNT(8); else G8_VMCNT(6);            // HA0(0), HB0(0) landed; four half-tiles behind them
+  ld_a(1, 0, l_sa); ld_b(1, 0, l_sb);
+  wait_young(0);                                             // HA0(0), HB0(0) landed; four half-tiles behind them
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one barrier behind group 0
 
-  int c_it = 0, c_k = 0, c_m0, c_n0, c_cmin;
+  int c_it = 0, c_m0, c_n0, c_cmin;
   tile_origin(0, c_m0, c_n0, c_cmin);
-  bool after_epi = false;
+  int p_m0 = 0, p_n0 = 0, p_cmin = 0;                        // the tile whose r1 rows are still to be stored
+  bool p_pending = false, p_full = false, p_second_full = false;
   const int total = my_tiles * nk;
-  for (int u = 0; u < total; ++u) {
-    const int buf = u & 1;
-    // the waits: everything older than the four youngest half-tiles (and, in the K step behind an epilogue, than the
-    // epilogue's stores) has landed
-#define G8_WAIT()                                                             \
-  do {                                                                        \
-    if (after_epi) {                                                          \
-      if (YOUNG + NST == 24) G8_VMCNT(24); else if (YOUNG + NST == 40) G8_VMCNT(40);       \
-      else if (YOUNG + NST == 14) G8_VMCNT(14); else if (YOUNG + NST == 22) G8_VMCNT(22);  \
-      else if (YOUNG == 8) G8_VMCNT(8); else G8_VMCNT(6);                     \
-    } else if (YOUNG == 8) G8_VMCNT(8); else G8_VMCNT(6);                     \
-  } while (0)
+  // One K step (buf is a compile-time constant so that seq[][] stays in registers).  `first`: first K step of its tile
+  // (compile time: zero-initialised MFMAs; the r1 rows of the previous tile leave in ph1, ph2); `last`: last K step of
+  // its tile (run time: the r0 rows leave in ph3, ph4).  A tile that is not stored in full (M edge, masked columns) may
+  // issue fewer stores than a count would assume: its stores are not counted, which only makes the waits stricter.
+  // Store batches T1 (ph3), T2 (ph4) of a tile's last K step u, T3 (ph1), T4 (ph2) of the next tile's first K step v.
+  // Batches younger than the load a wait is for:  u: ph4 +2   v: ph1 +3, ph2 +4, ph4 +2   v+1: ph1 +1.
+  auto kstep = [&](auto buf_tag, auto first_tag, bool second, bool last) {
+    constexpr int buf = decltype(buf_tag)::value;
+    constexpr bool first = decltype(first_tag)::value;
+    const bool full = c_m0 + BM <= P.M && c_n0 >= c_cmin && !ACCUM;
+    const bool pf = p_pending && p_full;                      // the previous tile's batches were issued in full
+    const int x4 = (last && full ? 2 : 0) + (first && pf ? 2 : 0);
     // ph1: r0 x c0
     read_a(buf, 0);
     read_b(buf, 0);
-    load_b(buf ^ 1, 1, l_sb);
-    G8_WAIT();
+    if (first && p_pending) store_rows(RH, p_m0, p_n0, p_cmin, p_full);
+    ld_b(buf ^ 1, 1, l_sb);
+    wait_young(first ? (pf ? 3 : 0) : (second && p_second_full ? 1 : 0));     // HB1 of this K step (read in ph2)
     G8_SEG_END();
-    G8_MMA(0, 0);
+    mma(0, 0, first);
     G8_MMA_END();
     // ph2: r0 x c1
     read_b(buf, 1);
-    load_a(buf ^ 1, 1, l_sa);
-    G8_WAIT();
+    if (first && p_pending) store_rows(RH + RH / 2, p_m0, p_n0, p_cmin, p_full);
+    ld_a(buf ^ 1, 1, l_sa);
+    wait_young(first && pf ? 4 : 0);                                          // HA1 of this K step (read in ph3)
     G8_SEG_END();
-    G8_MMA(0, 1);
+    mma(0, 1, first);
     G8_MMA_END();
     // ph3: r1 x c1
     read_a(buf, 1);
+    if (last) store_rows(0, c_m0, c_n0, c_cmin, full);
     cursor_next();
-    load_a(buf, 0, l_sa);
+    ld_a(buf, 0, l_sa);
     G8_SEG_END();
-    G8_MMA(1, 1);
+    mma(1, 1, first);
     G8_MMA_END();
     // ph4: r1 x c0
-    load_b(buf, 0, l_sb);
-    G8_WAIT();
+    if (last) store_rows(RH / 2, c_m0, c_n0, c_cmin, full);
+    ld_b(buf, 0, l_sb);
+    wait_young(x4);                                                           // HA0, HB0 of the next K step
     G8_SEG_END();
-    G8_MMA(1, 0);
+    mma(1, 0, first);
     G8_MMA_END();
-    after_epi = false;
-    if (++c_k == nk) {
-      // ---- epilogue: lane holds C[row][16 consecutive columns] per row tile
-      TOUT* C = (TOUT*)P.C;
-      const int col = c_n0 + wc * 64 + (sizeof(TOUT) == 2 ? fg * 8 : fg * 4);
-      const bool col_ok = c_n0 + wc * 64 >= c_cmin;
-      const bool full = c_m0 + BM <= P.M && c_n0 >= c_cmin;
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int row = c_m0 + g * GROUP_ROWS + i * 16 + fr;
-        if (row < P.M && col_ok && !(P.dbg & 1) && !((P.dbg & 32) && i >= RT / 2)) {
-          if constexpr (sizeof(TOUT) == 2) {
-            u32x4 lo = {pack_bf2(acc[i][0][0], acc[i][0][1]), pack_bf2(acc[i][0][2], acc[i][0][3]),
-                        pack_bf2(acc[i][1][0], acc[i][1][1]), pack_bf2(acc[i][1][2], acc[i][1][3])};
-            u32x4 hi = {pack_bf2(acc[i][2][0], acc[i][2][1]), pack_bf2(acc[i][2][2], acc[i][2][3]),
-                        pack_bf2(acc[i][3][0], acc[i][3][1]), pack_bf2(acc[i][3][2], acc[i][3][3])};
-            bf16_t* p = (bf16_t*)C + (size_t)row * P.ldc + col;
-            if (P.dbg & 2) {
-              __builtin_nontemporal_store(lo, (u32x4*)p);
-              __builtin_nontemporal_store(hi, (u32x4*)(p + 32));
-            } else {
-              *(u32x4*)p = lo;
-              *(u32x4*)(p + 32) = hi;
-            }
-          } else {
-            float* p = (float*)C + (size_t)row * P.ldc + col;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              f32x4 v = acc[i][j];
-              if (ACCUM) v += *(const f32x4*)(p + j * 16);
-              *(f32x4*)(p + j * 16) = v;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      c_k = 0;
+    if (first) { p_second_full = pf; p_pending = false; }
+    if (last) {
+      p_m0 = c_m0; p_n0 = c_n0; p_cmin = c_cmin; p_pending = true; p_full = full;
       ++c_it;
       if (c_it < my_tiles) tile_origin(c_it, c_m0, c_n0, c_cmin);
-      after_epi = full;             // the allowance below counts the stores of a tile stored in full
+    }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  // nk is even for every shape the launcher admits, so a tile always starts on buffer 0
+  for (int t = 0; t < my_tiles; ++t) {
+    kstep(B0{}, std::true_type{}, false, false);
+    kstep(B1{}, std::false_type{}, true, nk == 2);
+    for (int k = 2; k < nk; k += 2) {
+      kstep(B0{}, std::false_type{}, false, false);
+      kstep(B1{}, std::false_type{}, false, k + 2 == nk);
     }
   }
+  if (p_pending) { store_rows(RH, p_m0, p_n0, p_cmin, false); store_rows(RH + RH / 2, p_m0, p_n0, p_cmin, false); }
   G8_VMCNT(0);
   if (g == 0) __builtin_amdgcn_s_barrier();                  // pairs with group 1's extra barrier at the start
-}
-
-static int g8_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
 }
 
 // Returns 1 if the shape was launched on the second-generation kernel, 0 if the caller should use gemm.hip's.
 int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        int out_dtype, int accumulate, hipStream_t s) {
-  if (M < 4096 || N < 256 || N % 128 != 0 || K % 64 != 0 || K < 128) return 0;
+  if (M < 4096 || N < 256 || N % 128 != 0 || K % 128 != 0 || K < 128) return 0;      // (an even number of K steps)
+  // Shapes this kernel is measured to win on (profiles/r02_gemm_ab.txt).  Not: a last column tile that is half
+  // overlap (N % 256 == 128: qkv 1152, cq 384 — 11-33 % of the MFMAs redone), a tile count that leaves a fractional
+  // wave of workgroups (ckv: 384 tiles on 256 CUs), the accumulate form (one launch per decoder layer).
+  {
+    const char* force = getenv("MRMT3_GEMM8_ALL");             // tuning: take every admissible shape
+    if (!(force && force[0] == '1')) {
+      if (N % 256 != 0 || accumulate) return 0;
+      const int cu = g8_cus() & ~7, t256 = ceil_div(M, 256) * (N / 256);
+      const int nt = t256 < cu ? ceil_div(M, 128) * (N / 256) : t256;
+      if (nt % cu != 0 && nt < 6 * cu) return 0;
+    }
+  }
   if (((size_t)M * lda + K) * 2 >= 0x7FFF0000ull || ((size_t)N * ldb + K) * 2 >= 0x7FFF0000ull) return 0;
   G8Params P;
   P.A = (const bf16_t*)A; P.B = (const bf16_t*)B; P.C = C;
@@ -364,6 +443,7 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
   }
   int grid = P.n_tiles < cus ? ((P.n_tiles + 7) & ~7) : cus;
   if (grid > P.n_tiles) grid = (P.n_tiles + 7) & ~7;
+  { const char* e = getenv("MRMT3_GEMM8_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e) & ~7; }   // diagnostics
 #define G8_LAUNCH(TOUT, ACC)                                                                                     \
   do {                                                                                                           \
     if (small) hipLaunchKernelGGL((gemm_nt8_kernel<TOUT, ACC, 4>), dim3((unsigned)grid), dim3(512), 0, s, P);   \

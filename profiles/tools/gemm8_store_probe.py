@@ -21,7 +21,7 @@ for M, N, K in ((65536, 2048, 512), (65536, 2048, 2048)):
     a = torch.randn(M, K, device=dev).bfloat16(); b = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     tiles = M // 256 * N // 256 / 256
-    for dbg, what in ((0, "as shipped"), (1, "no stores"), (3, "nt stores"), (5, "no stores, cache-hot loads"), (9, "no stores, no fragment reads"),
+    for dbg, what in ((0, "as shipped"), (1, "no stores"), (2, "plain (not streaming) stores"), (32, "half of the stores"), (5, "no stores, cache-hot loads"), (9, "no stores, no fragment reads"),
                       (17, "no stores, loads off"), (25, "no stores, no reads, loads off (barriers + MFMA only)")):
         os.environ["MRMT3_GEMM8_DBG"] = str(dbg)
         t = timeit(lambda: lib.gemm_nt(a, b, out=out))

@@ -14,6 +14,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
 lib.load()
+os.environ.setdefault("MRMT3_GEMM8_ALL", "1")      # A/B every admissible shape, not only the ones the dispatch rule takes
 Md, Me = 65536, 16384
 # (name, M, N, K, out dtype, launches per step)
 NT = [("qkv", Md, 1152, 512, "bf16", 8), ("o/co", Md, 512, 384, "bf16", 16), ("cq", Md, 384, 512, "bf16", 8),

@@ -716,3 +716,46 @@ def test_gemm_tn_deferred_batch_is_bitwise_the_immediate_form(dev):
     lib.gemm_tn(a, b, big[384:768], accumulate=False, defer=batch)
     batch.flush()
     assert torch.equal(big[384:768], ref) and big[:384].abs().max() == 0 and big[768:].abs().max() == 0
+
+
+@pytest.mark.parametrize("M,N,K,out,acc", [
+    (65536, 512, 384, "bf16", False), (16384, 2048, 512, "bf16", False), (65536, 512, 2048, "bf16", False),
+    (65536, 1536, 512, "f32", False), (16384, 512, 768, "f32", True),
+    (4096 + 200, 1152, 512, "bf16", False),      # ragged M (zero-filled rows, masked stores) + half-overlapping last column tile
+    (8192, 384, 128, "bf16", False),             # two K steps per tile: first, second and last K step coincide
+    (4096, 768, 256, "f32", False)])
+def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypatch, M, N, K, out, acc):
+    """csrc/gemm8.hip (ping-pong phases, LDS-DMA two K steps ahead, epilogue spread over four phases with counted
+    waits) on every admissible shape class: against an f32 torch product on ALL rows, and against gemm.hip's kernel
+    (same MFMA, same k order: expected bit-identical for f32 output)."""
+    from mrmt3 import lib
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev).bfloat16()
+    b = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    dt = torch.bfloat16 if out == "bf16" else torch.float32
+    base = torch.randn(M, N, device=dev).to(dt) if acc else torch.zeros(M, N, device=dev, dtype=dt)
+    res = {}
+    for which in ("0", "1"):
+        monkeypatch.setenv("MRMT3_GEMM8", which)
+        monkeypatch.setenv("MRMT3_GEMM8_ALL", "1")
+        c = base.clone()
+        for _ in range(2 if acc else 1):
+            lib.gemm_nt(a, b, out=c, accumulate=acc)
+        res[which] = c
+    ref = a.float() @ b.float().t()
+    if acc:
+        ref = base.float() + 2 * ref
+    err = (res["1"].float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (6e-3 if out == "bf16" else 2e-6), err
+    if out == "f32":
+        assert torch.equal(res["0"], res["1"])
+    else:
+        assert (res["0"].float() - res["1"].float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    # operands and output as column slices of wider buffers (q | k | v views of the fused projection)
+    monkeypatch.setenv("MRMT3_GEMM8", "1")
+    wide_a = torch.randn(M, K + 128, device=dev).bfloat16()
+    wide_c = torch.zeros(M, N + 256, device=dev, dtype=dt)
+    lib.gemm_nt(wide_a[:, 128:], b, out=wide_c[:, 256:])
+    ref2 = wide_a[:, 128:].float() @ b.float().t()
+    assert (wide_c[:, 256:].float() - ref2).abs().max().item() / ref2.abs().max().item() < (6e-3 if out == "bf16" else 2e-6)
+    assert wide_c[:, :256].abs().max().item() == 0
