@@ -467,10 +467,20 @@ struct TnSite {             // = mrmt3_tn_site (include/mrmt3_hip.h)
   int N1, N2, ldc, splits, accumulate, block0, pad0, pad1;
 };
 __global__ __launch_bounds__(256) void slab_reduce_sites_kernel(const TnSite* __restrict__ sites, int n_sites) {
-  // site of this workgroup: block0 is ascending, n_sites is small (a scalar scan)
-  int si = 0;
-  while (si + 1 < n_sites && (int)blockIdx.x >= sites[si + 1].block0) ++si;
-  const TnSite st = sites[si];
+  // site of this workgroup: block0 is ascending.  (A scan of the table in global memory is n_sites DEPENDENT scalar
+  // loads per workgroup — with 45 sites that was most of the kernel's 586 us; one wave-wide load + ballot instead.)
+  __shared__ int s_site;
+  if (threadIdx.x < 64) {
+    int cnt = 0;
+    for (int base = 0; base < n_sites; base += 64) {
+      const int i = base + (int)threadIdx.x;
+      const bool le = i < n_sites && sites[i].block0 <= (int)blockIdx.x;
+      cnt += __popcll(__ballot(le));
+    }
+    if (threadIdx.x == 0) s_site = cnt - 1;
+  }
+  __syncthreads();
+  const TnSite st = sites[s_site];
   const float* __restrict__ slab = (const float*)st.slabs;
   float* __restrict__ C = (float*)st.C;
   const size_t n = (size_t)st.N1 * st.N2;
@@ -492,7 +502,18 @@ __global__ __launch_bounds__(256) void slab_reduce_sites_kernel(const TnSite* __
   *(f32x4*)p = s;
 }
 
+// gemm_tn8.hip: the ping-pong kernel for the large weight gradients
+int mrmt3_tn8_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per_split);
+int mrmt3_tn8_launch(const void* A, int lda, const void* B, int ldb, float* slab, int M, int N1, int N2, int tiles,
+                     int splits, int rps, hipStream_t s);
+static bool use_tn8(int M, int N1, int N2, int* tiles, int* splits, int* rps) {
+  const char* e = getenv("MRMT3_TN8");              // tuning / A-B switch only
+  if (e && e[0] == '0') return false;
+  return mrmt3_tn8_plan(M, N1, N2, tiles, splits, rps) != 0;
+}
+
 static void tn_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per_split) {
+  if (use_tn8(M, N1, N2, tiles, splits, rows_per_split)) return;
   const int t = ceil_div(N1, TILE) * ceil_div(N2, TILE);
   const int steps = ceil_div(M, TN_ROWS);
   const int max_s = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps (512 rows) per split
@@ -536,6 +557,14 @@ extern "C" int mrmt3_gemm_tn_partial(const void* A, int lda, const void* B, int 
   int tiles, splits, rps;
   tn_plan(M, N1, N2, &tiles, &splits, &rps);
   MR_CHECK_ARG(slab_bytes >= (size_t)splits * N1 * N2 * sizeof(float), "gemm_tn_partial: slab buffer too small");
+  {
+    int t8, s8, r8;
+    if (use_tn8(M, N1, N2, &t8, &s8, &r8)) {
+      mrmt3_tn8_launch(A, lda, B, ldb, (float*)slabs, M, N1, N2, t8, s8, r8, (hipStream_t)stream);
+      MR_CHECK_LAUNCH("gemm_tn8");
+      return MRMT3_OK;
+    }
+  }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((tiles * splits + 7) & ~7)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)slabs, M, N1, N2, ceil_div(N2, TILE), tiles,
                      splits, rps);
@@ -562,8 +591,13 @@ extern "C" int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, flo
   tn_plan(M, N1, N2, &tiles, &splits, &rps);
   MR_CHECK_ARG(workspace_bytes >= (size_t)splits * N1 * N2 * sizeof(float), "gemm_tn: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((tiles * splits + 7) & ~7)), dim3(256), 0, s, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, (float*)workspace, M, N1, N2, ceil_div(N2, TILE), tiles, splits, rps);
+  int t8, s8, r8;
+  if (use_tn8(M, N1, N2, &t8, &s8, &r8)) {
+    mrmt3_tn8_launch(A, lda, B, ldb, (float*)workspace, M, N1, N2, t8, s8, r8, s);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((tiles * splits + 7) & ~7)), dim3(256), 0, s, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, (float*)workspace, M, N1, N2, ceil_div(N2, TILE), tiles, splits, rps);
+  }
   MR_CHECK_LAUNCH("gemm_tn");
   const size_t n = (size_t)N1 * N2;
   int blocks = (int)((n / 4 + 255) / 256);
