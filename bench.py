@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--extra-batch", type=int, default=12, help="also time this per-GPU batch (0 = off)")
     return ap.parse_args()
 
 
@@ -64,6 +65,11 @@ def build_model(variant, dev, dtype=torch.bfloat16):
         from models.t5_segmem_v2_with_prev import T5SegMemV2WithPrev
         m = T5SegMemV2WithPrev(T5_SMALL, 1, 64, compute_dtype=dtype)
     return m.load_golden().to(dev)
+
+
+def tn_slab_bytes(batch):
+    """Bytes the batched split-K reduction streams (all queued sites' slabs)."""
+    return sum(batch._slabs[k].numel() for k in batch._queue) if batch is not None else 0
 
 
 def roofline_pass(trainer, audio, labels, prev, steps):
@@ -105,31 +111,66 @@ def cpu_baseline(seconds):
     dt = time.perf_counter() - t0
     out = dict(value=n / dt, unit="segments/s", cores=torch.get_num_threads(), kind="port",
                sample="%d x (log-mel + fwd + CE + bwd) of 1 segment (no optimizer, no dropout), fp32 torch CPU oracle, %.1f s" % (n, dt))
-    # per-stage figures of the same port: a few repetitions each, bounded to a few seconds
+    # per-stage figures of the same port (BASELINE.md §2 / SURVEY §8d): a few repetitions each, bounded to ~40 s in all
     def best(fn, reps):
         ts = []
         for _ in range(reps):
             t = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t)
-        return min(ts)
+        return min(ts), sum(ts) / len(ts)
     sd_ng = {k: v.detach() for k, v in sd.items()}
     mel1 = torch.from_numpy(logmel_ref.logmel_segments(audio))
+    sd_dec = dict(sd_ng)
+    sd_dec["lm_head.weight"] = sd_ng["lm_head.weight"].clone()
+    sd_dec["lm_head.weight"][1].zero_()                      # EOS never wins: every requested step runs
+    stages = {"threads": cores}
     with torch.no_grad():
-        stages = {
-            "log_mel_ms_per_segment": 1e3 * best(lambda: logmel_ref.logmel_segments(audio), 3),
-            "fwd_loss_ms_per_segment": 1e3 * best(lambda: t5_ref.ce_loss(t5_ref.forward_logits(sd_ng, T5_SMALL, mel1, lab), lab), 2),
-            # the reference's own decode algorithm (no KV cache, full prefix recompute), 64 tokens, 1 segment
-            "greedy_no_cache_64_tokens_s": best(lambda: t5_ref.generate_t5(sd_ng, T5_SMALL, mel1, max_length=64), 1),
-        }
-    stages["rtf_no_cache_64_tokens"] = stages["greedy_no_cache_64_tokens_s"] / SEG_SECONDS
-    # the same fwd + CE + bwd at 8 threads (SURVEY 8d asks for N = 8 next to the larger pool)
-    torch.set_num_threads(min(8, cores))
-    def one_step():
-        loss = t5_ref.ce_loss(t5_ref.forward_logits(sd, T5_SMALL, mel1, lab), lab)
+        stages["log_mel_ms_per_segment"] = 1e3 * best(lambda: logmel_ref.logmel_segments(audio), 3)[0]
+        mn, mean = best(lambda: t5_ref.ce_loss(t5_ref.forward_logits(sd_ng, T5_SMALL, mel1, lab), lab), 3)
+        stages["fwd_loss_b1_ms"] = {"min": 1e3 * mn, "mean": 1e3 * mean}
+        # the reference's own decode algorithm (no KV cache, full prefix recompute), one segment
+        for n_tok in (64, 128, 256):
+            t = best(lambda: t5_ref.generate_t5(sd_dec, T5_SMALL, mel1, max_length=n_tok), 1)[0]
+            stages["greedy_no_cache_%d_tokens_s" % n_tok] = t
+            stages["rtf_no_cache_%d_tokens" % n_tok] = t / SEG_SECONDS
+        # the cached algorithm (what the HIP decoder does), all 1024 tokens
+        t = best(lambda: t5_ref.generate_t5_cached(sd_dec, T5_SMALL, mel1, max_length=1024), 1)[0]
+        stages["greedy_cached_1024_tokens_s"] = t
+        stages["rtf_cached_1024_tokens"] = t / SEG_SECONDS
+
+    def fwd_bwd(sdict, melb, labb, **kw):
+        loss = t5_ref.ce_loss(t5_ref.forward_logits(sdict, T5_SMALL, melb, labb, **kw), labb)
         loss.backward()
-    stages["fwd_bwd_8_threads_segments_per_s"] = 1.0 / best(one_step, 3)
+    mel4 = mel1.repeat(4, 1, 1)
+    lab4 = torch.from_numpy(synth_labels(4))
+    mn, mean = best(lambda: fwd_bwd(sd, mel4, lab4), 2)
+    stages["fwd_bwd_b4_segments_per_s"] = {"best": 4.0 / mn, "mean": 4.0 / mean}
+    # MR-MT3 proper: segment memory from the previous segment's tokens (64 slots)
+    sd_seg = {k: torch.from_numpy(v).requires_grad_(True) for k, v in golden_weights(T5_SMALL, 1).items()}
+    prev1 = torch.from_numpy(synth_labels(1, seed=1365))
+    mn, mean = best(lambda: fwd_bwd(sd_seg, mel1, lab, variant="segmem_v2_with_prev", targets_prev=prev1.clone()), 2)
+    stages["segmem_v2_with_prev_fwd_bwd_b1_segments_per_s"] = {"best": 1.0 / mn, "mean": 1.0 / mean}
+    # the same fwd + CE + bwd at 8 threads (BASELINE.md §2 asks for N = 8 next to the larger pool) ...
+    torch.set_num_threads(min(8, cores))
+    mn, mean = best(lambda: fwd_bwd(sd, mel1, lab), 3)
+    stages["fwd_bwd_b1_8_threads_segments_per_s"] = {"best": 1.0 / mn, "mean": 1.0 / mean}
     torch.set_num_threads(cores)
+    # ... and at N = every core of the host, in a child process with a deadline: torch's intra-op pool collapses far
+    # below this host's core count on T5-small sized matmuls (round 1: 256 threads took 296 s per step)
+    ncpu = os.cpu_count() or cores
+    if ncpu > cores:
+        code = ("import sys,time,torch;sys.path[:0]=[%r,%r];from mrmt3.synthetic import T5_SMALL,golden_weights,synth_mel,synth_labels;"
+                "from oracle import t5_ref;torch.set_num_threads(%d);sd={k:torch.from_numpy(v) for k,v in golden_weights(T5_SMALL).items()};"
+                "mel=torch.from_numpy(synth_mel(1));lab=torch.from_numpy(synth_labels(1));f=lambda:t5_ref.ce_loss(t5_ref.forward_logits(sd,T5_SMALL,mel,lab),lab);"
+                "torch.no_grad().__enter__();f();t=time.perf_counter();f();print(time.perf_counter()-t)") % (
+                    os.path.join(ROOT, "mr-mt3_amd"), ROOT, ncpu)
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=45)
+            stages["fwd_loss_b1_all_%d_threads_ms" % ncpu] = 1e3 * float(r.stdout.strip().splitlines()[-1])
+        except Exception as e:     # deadline passed (or the child failed): say so instead of a number
+            stages["fwd_loss_b1_all_%d_threads_ms" % ncpu] = "no result within 45 s (%s)" % type(e).__name__
     try:
         with open("/proc/cpuinfo") as f:
             out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
@@ -160,8 +201,18 @@ def inference_rtf(dev, tokens, batch):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         assert ids.shape == (nb, tokens + 1)
+        # bytes one decode step has to move: 45.6 MB of bf16 decoder weights + lm_head (once per step for
+        # every group of 16 sequences above 8, once per sequence below) + this step's K/V: the self-attention cache
+        # (mean length tokens/2) and the projected encoder states (256 frames), 8 layers x 2 x 384 x 2 B per position
+        w_bytes = 45.6e6 * (nb if nb <= 8 else -(-nb // 16))
+        kv_bytes = nb * 8 * 2 * 384 * 2 * (tokens / 2 + 256)
+        step_s = dt / tokens
         out[name] = dict(segments=nb, tokens=tokens, seconds=dt, rtf=dt / (nb * SEG_SECONDS),
-                         ms_per_token_step=1e3 * dt / tokens, graph=bool(m._decoder.graph_captured))
+                         ms_per_token_step=1e3 * step_s, graph=bool(m._decoder.graph_captured),
+                         roofline_decode={"bound": "hbm", "bytes_per_step": w_bytes + kv_bytes,
+                                          "achieved": (w_bytes + kv_bytes) / step_s / 1e9, "peak": PEAK_HBM_GBS,
+                                          "unit": "GB/s", "frac": (w_bytes + kv_bytes) / step_s / 1e9 / PEAK_HBM_GBS,
+                                          "launch_chain_floor_ms": 66 * 1.77e-3})
     # MR-MT3 proper (segment memory from the previous segment's tokens): a recording is a sequential chain,
     # several recordings decode in lockstep, one batch row each
     del m
@@ -246,6 +297,22 @@ def main():
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
         "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
+    if rank == 0 and world == 1 and args.extra_batch > 0:
+        # the reference's own per-GPU batch (config_slakh_segmem.yaml: num_rows_per_batch 12)
+        Bx = args.extra_batch
+        ax, lx = audio[:Bx].contiguous(), labels[:Bx].contiguous()
+        px = None if prev is None else prev[:Bx].contiguous()
+        for _ in range(4):
+            trainer.train_step(ax, lx, None if px is None else px.clone(), audio=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_step(ax, lx, None if px is None else px.clone(), audio=True)
+        torch.cuda.synchronize()
+        dtx = time.perf_counter() - t1
+        res["train_b%d" % Bx] = {"segments_per_gpu": Bx, "ms_per_step": 1e3 * dtx / args.steps,
+                                 "segments_per_s": Bx * args.steps / dtx,
+                                 "model_tflops": Bx * args.steps / dtx * FLOP_PER_SEG_FWD_BWD / 1e12}
     if not args.no_roofline:
         # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings.
         # Pass 1 is the timed configuration: weight-gradient GEMMs run on a second stream, so a launch's
@@ -267,10 +334,27 @@ def main():
             return v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "FLOP" else 1e9)
 
         f, fi = fam[dom], fam_iso[dom]
+        # HBM traffic of the dominant family: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction
+        # of MI355X_MICROARCH.md) cannot run inside this process; the per-shape table they produced for this tree is
+        # committed (profiles/r02_pmc_gemm_traffic.json, made by profiles/tools/pmc_traffic.sh) and folded in here
+        # per launch: sum over the step's launches of the measured bytes / number of launches.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")) as fh:
+                tab = json.load(fh)
+            traffic = {"bytes_per_launch": tab["nt_bytes_per_step"] / tab["nt_launches_per_step"],
+                       "algorithmic_bytes_per_launch": tab["nt_algorithmic_bytes_per_step"] / tab["nt_launches_per_step"],
+                       "ratio": tab["nt_bytes_per_step"] / tab["nt_algorithmic_bytes_per_step"],
+                       "source": "profiles/r02_pmc_gemm_traffic.json"}
+        except Exception:
+            pass
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": rate(f), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": rate(f) / PEAK_BF16_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": rate(f) / PEAK_BF16_TFLOPS, "traffic": traffic,
                            "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
-                           "note": "as timed: wgrad GEMMs overlap on a second stream, durations include CU sharing",
+                           "note": "per-launch events in an eager repeat of the timed steps (the timed steps themselves "
+                                   "replay hipGraphs); pass 1 overlaps the weight-gradient GEMMs on a second stream "
+                                   "(durations include CU sharing), `isolated` serialises everything on one stream "
+                                   "like the graph does",
                            "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam.items()},
                            "families_achieved": {k: rate(v) for k, v in fam.items()},
                            "isolated": {"achieved": rate(fi), "frac": rate(fi) / PEAK_BF16_TFLOPS,

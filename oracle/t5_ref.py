@@ -216,6 +216,53 @@ def generate_t5(sd, cfg, mel, max_length=1024, return_margins=False):
     return ids
 
 
+def generate_t5_cached(sd, cfg, mel, max_length=1024):
+    """The same greedy decode with a self-attention KV cache and the cross-attention K/V projected once (what any
+    efficient implementation does, the HIP path included).  NOT the reference's algorithm (`models/t5.py:267-295`
+    recomputes the whole prefix per token): it exists as the CPU baseline BASELINE.md §2 asks for next to the no-cache
+    one, and `tests/test_oracle_golden.py` checks that it returns the tokens `generate_t5` returns."""
+    H, eps, d = cfg["num_heads"], cfg["layer_norm_epsilon"], cfg["d_model"]
+    L = cfg["num_decoder_layers"]
+    B = mel.shape[0]
+    enc = encode(sd, cfg, mel)
+    pe = pos_emb(max_length + 1, d)[0]
+    blk = lambda i, n: sd[f"decoder.block.{i}.layer.{n}.weight"]
+    dk = blk(0, "0.SelfAttention.q").shape[0] // H
+    heads = lambda t: t.view(B, -1, H, dk).transpose(1, 2)
+    ck = [heads(enc @ blk(i, "1.EncDecAttention.k").t()) for i in range(L)]
+    cv = [heads(enc @ blk(i, "1.EncDecAttention.v").t()) for i in range(L)]
+    sk = [torch.zeros(B, H, max_length + 1, dk) for _ in range(L)]
+    sv = [torch.zeros(B, H, max_length + 1, dk) for _ in range(L)]
+    ids = torch.full((B, 1), cfg["decoder_start_token_id"], dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.long)
+
+    def attend(q, k, v, wo):
+        p = F.softmax((q @ k.transpose(2, 3)).float(), dim=-1)
+        return (p @ v).transpose(1, 2).reshape(B, 1, H * dk) @ wo.t()
+
+    for t in range(max_length):
+        x = sd["decoder_embed_tokens.weight"][ids[:, -1:]] + pe[t]
+        for i in range(L):
+            xn = rms_norm(x, blk(i, "0.layer_norm"), eps)
+            sk[i][:, :, t] = heads(xn @ blk(i, "0.SelfAttention.k").t())[:, :, 0]
+            sv[i][:, :, t] = heads(xn @ blk(i, "0.SelfAttention.v").t())[:, :, 0]
+            x = x + attend(heads(xn @ blk(i, "0.SelfAttention.q").t()), sk[i][:, :, :t + 1], sv[i][:, :, :t + 1],
+                           blk(i, "0.SelfAttention.o"))
+            xn = rms_norm(x, blk(i, "1.layer_norm"), eps)
+            x = x + attend(heads(xn @ blk(i, "1.EncDecAttention.q").t()), ck[i], cv[i], blk(i, "1.EncDecAttention.o"))
+            xn = rms_norm(x, blk(i, "2.layer_norm"), eps)
+            x = x + ff_gated_gelu(xn, blk(i, "2.DenseReluDense.wi_0"), blk(i, "2.DenseReluDense.wi_1"),
+                                  blk(i, "2.DenseReluDense.wo"))
+        logits = rms_norm(x, sd["decoder.final_layer_norm.weight"], eps)[:, 0] @ sd["lm_head.weight"].t()
+        nxt = logits.argmax(-1)
+        nxt = nxt * unfinished + cfg["pad_token_id"] * (1 - unfinished)
+        unfinished = unfinished * (nxt != cfg["eos_token_id"]).long()
+        ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        if unfinished.max() == 0:
+            break
+    return ids
+
+
 def generate_segmem_v2(sd, cfg, mel, max_length=1024, segmem_length=64, with_prev=True,
                        return_margins=False):
     """`T5SegMemV2WithPrev.generate` (`models/t5_segmem_v2_with_prev.py:226-296`; with_prev=False

@@ -88,3 +88,16 @@ def test_greedy_fixtures_are_not_knife_edge(golden):
                                              return_margins=True)
     np.testing.assert_array_equal(ids2.numpy(), golden["segmem_v2_with_prev.gen32"])
     assert min(min(m) for m in m2 if m) > 1e-3, min(min(m) for m in m2 if m)     # measured 1.8e-3
+
+
+def test_cached_greedy_decode_returns_the_reference_algorithms_tokens(golden):
+    """oracle.t5_ref.generate_t5_cached (KV cache; the CPU baseline of the cached decode) == the recorded output of the
+    reference's own no-cache `generate` on the golden inputs, token for token."""
+    import torch
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel
+    from oracle import t5_ref
+    sd = {k: torch.from_numpy(v) for k, v in golden_weights(T5_SMALL).items()}
+    mel = torch.from_numpy(synth_mel(2))
+    with torch.no_grad():
+        ids = t5_ref.generate_t5_cached(sd, T5_SMALL, mel, max_length=32)
+    np.testing.assert_array_equal(ids.numpy(), golden["t5.gen32"])
