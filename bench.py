@@ -242,7 +242,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no CPU fallback"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_coll = os.environ.get("MRMT3_DDP_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_coll:    # (force: the RCCL bucket path at world size 1, for the record in profiles/)
         dist.init_process_group("nccl", device_id=dev)
     from mrmt3 import lib
     lib.load()
@@ -294,6 +295,9 @@ def main():
         "final_loss": final_loss,
         "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
         "step_graph": bool(trainer.use_graph and trainer.graph_captured),
+        "graph_segments": (len(next(iter(trainer._graphs.values())).segments) + 1) if trainer._graphs else 0,
+        "collectives": ("rccl, %d buckets per step%s" % (len(trainer.buckets.buckets), " (forced at world 1)" if force_coll and world == 1 else "")
+                        if trainer.buckets.active else "none (world 1)"),
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
         "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
@@ -372,7 +376,7 @@ def main():
     sync()
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

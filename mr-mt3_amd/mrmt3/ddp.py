@@ -42,12 +42,28 @@ def layer_ranges(flat) -> "List[Tuple[str, int, int]]":
     return out
 
 
+class _Widen:
+    """A pending compressed bucket: wait() = wait for the collective, then copy the reduced values back as f32."""
+
+    def __init__(self, work, low, grad):
+        self.work, self.low, self.grad = work, low, grad
+
+    def wait(self):
+        self.work.wait()
+        self.grad.copy_(self.low)
+
+
 class GradBuckets:
     """Partition of the flat gradient buffer into buckets ordered by when backward completes them."""
 
     def __init__(self, flat, n_layers_enc: int, n_layers_dec: int, has_segmem: bool, layers_per_bucket: int = 2,
-                 group=None):
+                 group=None, exchange_dtype=None):
         self.flat, self.group = flat, group
+        # exchange_dtype=torch.bfloat16: each bucket is rounded to bf16, all-reduced in bf16 and widened back — half
+        # the bytes on the xGMI links (91.8 instead of 183.6 MB per step for MT3Net); the local f32 gradient is replaced
+        # by the reduced bf16 one, i.e. every rank still ends up with identical gradients.  Default: f32, like torch DDP.
+        self.exchange_dtype = exchange_dtype
+        self._staging = None
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         rng = {t: (a, b) for t, a, b in layer_ranges(flat)}
         self.ranges = rng
@@ -128,6 +144,8 @@ class GradBuckets:
         if self.before_fire is not None:
             self.before_fire()
         grad = self.flat.G[b["start"]:b["end"]]
+        if self.exchange_dtype is not None and self.exchange_dtype != grad.dtype:
+            return self._fire_compressed(b, grad)
         extra = [s for s in (self.producer_streams() if self.producer_streams is not None else []) if s is not None]
         if grad.is_cuda and extra:
             if self._launch is None or self._launch.device != grad.device:
@@ -139,6 +157,20 @@ class GradBuckets:
                 self._works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _fire_compressed(self, b, grad):
+        """Round the bucket to the exchange dtype, all-reduce that copy, widen it back into the f32 gradient when the
+        collective has finished (`wait()`).  The copies run on the current stream, behind the bucket's producers."""
+        if grad.is_cuda:
+            for s in (self.producer_streams() if self.producer_streams is not None else []):
+                if s is not None:
+                    torch.cuda.current_stream(grad.device).wait_stream(s)
+        if self._staging is None or self._staging.device != grad.device:
+            self._staging = torch.empty(self.flat.numel, dtype=self.exchange_dtype, device=grad.device)
+        low = self._staging[b["start"]:b["end"]]
+        low.copy_(grad)
+        work = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(_Widen(work, low, grad))
 
     def on_layer_done(self, prefix, i):
         """Engine callback: every gradient of `prefix` layer i (and above) is final."""

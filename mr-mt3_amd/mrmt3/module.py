@@ -48,7 +48,16 @@ class _ModelFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         model = ctx.model
         model.attach_grads()
-        model.engine.backward(ctx.tape, dlogits.contiguous(), on_layer_done=model._on_layer_done)
+        buckets = model._ddp_buckets()
+        if buckets is None:
+            model.engine.backward(ctx.tape, dlogits.contiguous(), on_layer_done=model._on_layer_done)
+        else:
+            # Several ranks and nobody else reduces these gradients (see MT3Module._ddp_buckets): do what torch DDP does
+            # for the reference — average them over the ranks, overlapped with the rest of backward.
+            buckets.reset()
+            model.engine.backward(ctx.tape, dlogits.contiguous(), on_layer_done=buckets.on_layer_done)
+            buckets.finish()
+            model.flat.G.mul_(1.0 / buckets.world)
         ctx.tape = None
         return None, None, None, None, None
 
@@ -143,6 +152,36 @@ class MT3Module(nn.Module):
     def device(self):
         return self.flat.P.device
 
+    def _ddp_buckets(self):
+        """The gradient exchange of the DROP-IN path (`loss.backward()` on the logits this module returned).
+
+        The reference wraps its task in torch DDP (`pl.Trainer(strategy="ddp_find_unused_parameters_false")`,
+        config/config.yaml:45, train.py:43-47).  The parameters of this module never enter the autograd graph (the
+        hand-written backward fills the flat gradient buffer), so DDP's reducer has no hooks to fire: wrapped in DDP, or
+        run under any multi-rank launcher without `mrmt3.trainer.Trainer`, every rank would silently keep its local
+        gradients and the replicas would drift apart.  So whenever a process group with more than one rank is
+        initialised and no `Trainer` owns the exchange (`_on_layer_done` unset), backward reduces the gradients itself
+        with the same bucketed all-reduce the Trainer uses and averages them (DDP semantics).  MRMT3_DDP_AUTO=0 turns
+        this off (then a multi-rank backward raises instead of diverging quietly)."""
+        import torch.distributed as dist
+        if self._on_layer_done is not None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        import os
+        if os.environ.get("MRMT3_DDP_AUTO", "1") == "0":
+            raise RuntimeError(
+                "MR-MT3 MI355X module under a multi-rank process group without a gradient exchange: its gradients live in "
+                "one flat buffer that torch DDP cannot see.  Use mrmt3.trainer.Trainer (bucketed RCCL all-reduce "
+                "overlapped with backward) or leave MRMT3_DDP_AUTO=1 so that backward() averages them itself.")
+        if getattr(self, "_auto_buckets", None) is None:
+            from .ddp import GradBuckets
+            b = GradBuckets(self.flat, self.cfg["num_layers"], self.cfg["num_decoder_layers"], self.segmem_num_layers > 0)
+            b.before_fire = self.engine.join_wgrad
+            b.producer_streams = lambda: [self.engine._side]
+            self._auto_buckets = b
+            # identical replicas to start from (DDP broadcasts rank 0's parameters at construction)
+            dist.broadcast(self.flat.P, src=0)
+        return self._auto_buckets
+
     def attach_grads(self):
         """Expose slices of the flat gradient buffer as `.grad` (zeroing it when grads were reset)."""
         G = self.flat.ensure_grads()
@@ -164,6 +203,7 @@ class MT3Module(nn.Module):
         if inputs is None or labels is None:
             raise ValueError("forward needs inputs (mel) and labels")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._views.values()):
+            self._ddp_buckets()        # several ranks and no Trainer: start from rank 0's weights (once), see there
             return _ModelFn.apply(self._anchor, self, inputs, labels, targets_prev)
         logits, _ = self.engine.forward(inputs, labels, targets_prev, training=self.training, need_grad=False)
         return logits

@@ -42,7 +42,7 @@ class _CapturedStep:
 class Trainer:
     def __init__(self, model, lr: float = 2e-4, lr_lambda=None, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.01, weighted_loss: bool = False, layers_per_bucket: int = 2,
-                 graph: bool = None):
+                 graph: bool = None, grad_exchange_dtype=None):
         self.model, self.flat, self.engine = model, model.flat, model.engine
         assert model.device.type == "cuda", "the trainer drives the HIP kernels: move the model to the GPU first"
         self.base_lr, self.lr_lambda = lr, lr_lambda
@@ -54,8 +54,10 @@ class Trainer:
         self.host_step = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         cfg = model.cfg
+        if grad_exchange_dtype is None and os.environ.get("MRMT3_GRAD_EXCHANGE", "f32") == "bf16":
+            grad_exchange_dtype = torch.bfloat16
         self.buckets = GradBuckets(self.flat, cfg["num_layers"], cfg["num_decoder_layers"],
-                                   model.segmem_num_layers > 0, layers_per_bucket)
+                                   model.segmem_num_layers > 0, layers_per_bucket, exchange_dtype=grad_exchange_dtype)
         self.buckets.before_fire = model.engine.join_wgrad      # norm-weight partials and split-K slabs are summed here
         self.buckets.producer_streams = lambda: [model.engine._side]
         self.flat.ensure_grads()
@@ -162,6 +164,7 @@ class Trainer:
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream()
         cs = self._cap_stream
+        torch.cuda.synchronize()           # nothing of the eager steps (collectives included) is in flight during capture
         eng.prepare(True)
         cap = _CapturedStep()
         cap.inputs, cap.labels = inputs.clone(), labels.clone()
@@ -171,11 +174,14 @@ class Trainer:
         state = {"g": None}
 
         def begin():
+            # thread-local capture mode: the process group's watchdog thread polls the events of earlier collectives
+            # (hipEventQuery) whenever it likes; under the default global mode that call is illegal while ANY thread
+            # captures and the watchdog takes the process down (seen with RCCL at world size 1, forced collectives)
             g = torch.cuda.CUDAGraph()
             if pool is None:
-                g.capture_begin()
+                g.capture_begin(capture_error_mode="thread_local")
             else:
-                g.capture_begin(pool=pool)
+                g.capture_begin(pool=pool, capture_error_mode="thread_local")
             state["g"] = g
 
         def cut(fire):

