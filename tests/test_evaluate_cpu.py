@@ -139,3 +139,35 @@ def test_evaluate_main_directory_layout(tmp_path, capsys):
     assert scores["F1 by program"] == {0: 1.0}
     with pytest.raises(ValueError):
         evaluate.evaluate_main("Other", "a", "b")
+
+
+def test_scores_equal_brute_force_optimal_matching_on_random_small_cases():
+    """contrib/transcription_metrics.py restates mir_eval's note matching (absent here: unpinned).  Property check
+    against an exhaustive search: for random small note sets the number of matched pairs equals the size of the LARGEST
+    one-to-one assignment among the pairs that satisfy the onset / pitch / offset rules, so precision / recall / F1 are
+    the optimum mir_eval defines (its matching is a maximum bipartite matching)."""
+    import itertools
+    from contrib import transcription_metrics as tm
+    rs = np.random.RandomState(5)
+    for case in range(60):
+        nr, ne = rs.randint(1, 7), rs.randint(1, 7)
+        ref_on = np.sort(rs.rand(nr) * 2.0)
+        ref = np.stack([ref_on, ref_on + 0.1 + rs.rand(nr) * 0.5], 1)
+        est_on = np.clip(ref_on[rs.randint(0, nr, ne)] + rs.randn(ne) * 0.04, 0, None)
+        est = np.stack([est_on, est_on + 0.1 + rs.rand(ne) * 0.5], 1)
+        rp = tm.midi_to_hz(rs.randint(60, 64, nr).astype(float))
+        ep = tm.midi_to_hz(rs.randint(60, 64, ne).astype(float))
+        for offset_ratio in (None, 0.2):
+            p, r, f, _ = tm.precision_recall_f1_overlap(ref, rp, est, ep, offset_ratio=offset_ratio)
+            ok = np.abs(np.subtract.outer(ref[:, 0], est[:, 0])).round(4) <= 0.05
+            ok &= np.abs(1200 * np.subtract.outer(np.log2(rp), np.log2(ep))) <= 50.0
+            if offset_ratio is not None:
+                tol = np.maximum(offset_ratio * (ref[:, 1] - ref[:, 0]), 0.05)
+                ok &= np.abs(np.subtract.outer(ref[:, 1], est[:, 1])).round(4) <= tol[:, None]
+            best = 0
+            small, big, mat = (nr, ne, ok) if nr <= ne else (ne, nr, ok.T)
+            for perm in itertools.permutations(range(big), small):
+                best = max(best, sum(mat[i, j] for i, j in enumerate(perm)))
+                if best == small:
+                    break
+            assert abs(p - best / ne) < 1e-12 and abs(r - best / nr) < 1e-12, (case, offset_ratio, p, r, best)

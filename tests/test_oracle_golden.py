@@ -101,3 +101,39 @@ def test_cached_greedy_decode_returns_the_reference_algorithms_tokens(golden):
     with torch.no_grad():
         ids = t5_ref.generate_t5_cached(sd, T5_SMALL, mel, max_length=32)
     np.testing.assert_array_equal(ids.numpy(), golden["t5.gen32"])
+
+
+def test_logmel_oracle_against_an_independent_float64_dft_and_analytic_triangles():
+    """The frontend oracle is a restatement of torchaudio's algorithm through torch.stft + a transcription of
+    melscale_fbanks; torchaudio is absent, so it stays "parity unpinned" — but a shared misuse of torch.stft (window
+    periodicity, centring, normalisation, one-sided layout) or of the filterbank formula would go unnoticed by every
+    test that compares the HIP kernel with it.  This check shares NOTHING with it: a direct O(N^2) DFT in float64 of the
+    hann-windowed frames, and the HTK triangles evaluated analytically in float64 from the definition
+    (contrib/spectrograms.py:128-145: n_fft 2048, hop 128, power 1, 512 mels from 20 to 7600 Hz, norm None)."""
+    from oracle import logmel_ref
+    rs = np.random.RandomState(11)
+    audio = (rs.rand(2048 + 3 * 128).astype(np.float32) * 2 - 1)
+    got = logmel_ref.compute_spectrogram(audio)                     # [frames, 512], natural log of the mel magnitudes
+    n = np.arange(2048)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * n / 2048)                  # periodic hann
+    k = np.arange(1025)
+    dft = np.exp(-2j * np.pi * np.outer(k, n) / 2048)               # [1025, 2048]
+    freqs = k * (16000 / 2) / 1024                                  # linspace(0, 8000, 1025)
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    m_pts = np.linspace(mel(20.0), mel(7600.0), 514)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    fb = np.zeros((1025, 512))
+    for m in range(512):
+        lo, ce, hi = f_pts[m], f_pts[m + 1], f_pts[m + 2]
+        fb[:, m] = np.maximum(0.0, np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce)))
+    padded = np.concatenate([audio.astype(np.float64), np.zeros(4096)])
+    for frame in (0, 1, 3):                                          # frame 3 still lies inside the real samples
+        x = padded[frame * 128: frame * 128 + 2048] * win
+        mag = np.abs(dft @ x)
+        want = np.log(np.where(mag @ fb <= 0, 1e-5, mag @ fb))
+        live = (mag @ fb) > 1e-3
+        assert np.abs(got[frame][live] - want[live]).max() < 2e-4, (frame, np.abs(got[frame][live] - want[live]).max())
+        assert (got[frame][~live] < np.log(2e-3)).all()
+    # and the filterbank itself: same non-zero pattern and values as the restated torchaudio formula (f32)
+    fb_ref = logmel_ref.melscale_fbanks().numpy()
+    assert ((fb_ref > 0) == (fb > 1e-9)).mean() > 0.9999 and np.abs(fb_ref - fb).max() < 2e-4
