@@ -759,3 +759,44 @@ def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypa
     ref2 = wide_a[:, 128:].float() @ b.float().t()
     assert (wide_c[:, 256:].float() - ref2).abs().max().item() / ref2.abs().max().item() < (6e-3 if out == "bf16" else 2e-6)
     assert wide_c[:, :256].abs().max().item() == 0
+
+
+def test_gemm8_and_tn8_race_screen_bitwise_repeatable_under_load(dev, monkeypatch):
+    """The ping-pong kernels order every LDS hand-off by counted vmcnt + barriers (no fences): a misplaced wait shows up
+    as rare wrong tiles that come and go with timing.  Screen: 150 back-to-back launches per shape, alternating with a
+    bandwidth-heavy kernel (different timing every time), every result bit-identical to the first and equal to an f32
+    reference."""
+    from mrmt3 import lib
+    monkeypatch.setenv("MRMT3_GEMM8_ALL", "1")
+    monkeypatch.setenv("MRMT3_TN8_ALL", "1")
+    torch.manual_seed(3)
+    noise = torch.empty(64 << 20, device=dev)
+    for M, N, K in ((16384, 512, 384), (65536, 1152, 512), (32768, 2048, 128)):
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        first = lib.gemm_nt(a, b, out_dtype=torch.float32).clone()
+        ref = a.float() @ b.float().t()
+        assert (first - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-6
+        out = torch.empty_like(first)
+        bad = 0
+        for it in range(150):
+            if it % 3 == 0:
+                noise.fill_(float(it))
+            lib.gemm_nt(a, b, out=out)
+            bad += int(not torch.equal(out, first))
+        assert bad == 0, (M, N, K, bad)
+    for M, N1, N2 in ((65536, 512, 1024), (32768, 1152, 512)):
+        a = (torch.randn(M, N1, device=dev) * 0.1).bfloat16()
+        b = (torch.randn(M, N2, device=dev) * 0.1).bfloat16()
+        first = torch.zeros(N1, N2, device=dev)
+        lib.gemm_tn(a, b, first)
+        ref = a.float().t() @ b.float()
+        assert (first - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+        out = torch.empty_like(first)
+        bad = 0
+        for it in range(100):
+            if it % 3 == 0:
+                noise.fill_(float(it))
+            lib.gemm_tn(a, b, out)
+            bad += int(not torch.equal(out, first))
+        assert bad == 0, (M, N1, N2, bad)
