@@ -18,6 +18,10 @@
  *  - Every call is asynchronous on the hipStream_t passed as `void* stream`, re-entrant across
  *    streams, never synchronises the device and never allocates (graph-capture safe).  The only
  *    library-owned objects are the opaque mrmt3_decoder handles.
+ *  - Dropout: every entry point that draws a mask takes (p_drop, seed, step_dev, stream id): the mask is a pure function
+ *    of (seed, stream id, element index) salted, when step_dev is not NULL, by the int32 it points to in DEVICE memory —
+ *    read by the kernel at run time, so a captured hipGraph draws new masks every optimizer step (mrmt3_adamw_step
+ *    increments the counter).  Forward and backward of a site must pass the same four values.
  *  - Return value: 0 = MRMT3_OK, otherwise an error code; mrmt3_last_error() returns a
  *    thread-local message.  Nothing aborts or throws across this ABI.
  */
@@ -191,6 +195,17 @@ int mrmt3_ce_count(const int64_t* targets, int rows, int weighted, int inst_lo, 
 int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* denom_dev,
                      float* loss_dev, void* dlogits, int dl_dtype, int rows, int V, int weighted,
                      int inst_lo, int inst_hi, float grad_scale, void* stream);
+
+/* lm_head + cross-entropy without the [rows][V] f32 logits in memory (models/t5.py:72,176-180 followed by
+ * tasks/mt3_net.py:32-35).  dec [rows][ld_dec] bf16 = the final-normed decoder states, W [V][ldw] bf16 = lm_head.weight.
+ * Rows are processed in chunks of chunk_rows: logits of a chunk = dec_chunk . W^T go (f32) into `workspace`
+ * (>= min(rows, chunk_rows)*V*4 bytes, reused by every chunk), then exactly mrmt3_ce_fwd_bwd on that chunk: loss_dev[0]
+ * accumulates, dlogits [rows][V] (dl_dtype; nullable: loss only) receives the gradient.  denom_dev as for
+ * mrmt3_ce_fwd_bwd (run mrmt3_ce_count over ALL targets first; zero loss_dev first). */
+int mrmt3_lmhead_ce_fwd_bwd(const void* dec, int ld_dec, const void* W, int ldw, const int64_t* targets,
+                            const float* denom_dev, float* loss_dev, void* dlogits, int dl_dtype, int rows, int V,
+                            int d, int weighted, int inst_lo, int inst_hi, float grad_scale, void* workspace,
+                            size_t workspace_bytes, int chunk_rows, void* stream);
 
 /* ---- K11: AdamW over the flat parameter buffer (torch.optim.AdamW defaults; tasks/mt3_net.py:55)
  * p,g,m,v: flat f32 [n].  lr is read from lr_dev[0] (device), step count from step_dev[0] (int32,

@@ -400,8 +400,10 @@ class Engine:
         return torch.cat([dummy, seg[:-1]], 0).contiguous()
 
     # ---- full forward / backward --------------------------------------------------------------------------
-    def forward(self, mel, labels, targets_prev=None, training=False, need_grad=False):
-        """Returns (logits [B, Ld, V] fp32, tape or None).  Mirrors get_model_outputs of the four
+    def forward(self, mel, labels, targets_prev=None, training=False, need_grad=False, want_logits=True):
+        """Returns (logits [B, Ld, V] fp32, tape or None) — or, with want_logits=False, the final-normed decoder states
+        [B*Ld, d] in the compute dtype instead of the logits (the trainer feeds them to the fused lm_head + CE call, so
+        the 403 MB of f32 logits of a 64-segment batch never exist).  Mirrors get_model_outputs of the four
         reference model classes (models/t5.py:99-180, t5_segmem.py:68-170, t5_segmem_v2.py:64-167,
         t5_segmem_v2_with_prev.py:60-153)."""
         cfg, f = self.cfg, self.flat
@@ -460,10 +462,12 @@ class Engine:
                              out_dtype=torch.float32 if head_f32 else None)
         if variant == "segmem_v1":
             dec = dec.view(B, Lx, d)[:, Ls:].contiguous().view(B * Ld, d)
-        w_head = f.W("lm_head", torch.float32) if head_f32 else self.W("lm_head")
-        logits = lib.gemm_nt(dec, w_head, out_dtype=torch.float32)               # [B*Ld, V]
         if tape is not None:
             tape.push(kind="head", dec=dec)
+        if not want_logits:
+            return dec, tape
+        w_head = f.W("lm_head", torch.float32) if head_f32 else self.W("lm_head")
+        logits = lib.gemm_nt(dec, w_head, out_dtype=torch.float32)               # [B*Ld, V]
         return logits.view(B, Ld, self.V), tape
 
     def backward(self, tape, dlogits, on_layer_done=None):

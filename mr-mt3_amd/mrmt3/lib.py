@@ -50,6 +50,7 @@ _SIGS = {
     "mrmt3_dropmask_cast": (ci, [vp, vp, csz, cf, cu64, vp, cu32, vp]),
     "mrmt3_ce_count": (ci, [vp, ci, ci, ci, ci, vp, vp]),
     "mrmt3_ce_fwd_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]),
+    "mrmt3_lmhead_ce_fwd_bwd": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, csz, ci, vp]),
     "mrmt3_adamw_step": (ci, [vp, vp, vp, vp, csz, vp, vp, cf, cf, cf, cf, cf, vp, vp]),
     "mrmt3_transpose": (ci, [vp, ci, vp, ci, ci, ci, vp]),
     "mrmt3_cast": (ci, [vp, ci, vp, ci, csz, vp]),
@@ -468,6 +469,27 @@ def cross_entropy(logits, targets, want_grad=True, grad_dtype=torch.bfloat16, we
     _check(lib.mrmt3_ce_fwd_bwd(_p(logits), _p(targets), C.c_void_p(acc.data_ptr() + 4), _p(acc), _p(dl),
                                 _dt(dl) if dl is not None else F32, rows, V, int(weighted), inst_lo, inst_hi,
                                 grad_scale, _stream()), "ce_fwd_bwd")
+    return acc[0:1], dl
+
+
+def lmhead_cross_entropy(dec, w, targets, want_grad=True, grad_dtype=torch.bfloat16, weighted=False, inst_lo=1135,
+                         inst_hi=1262, grad_scale=1.0, chunk_rows=16384):
+    """lm_head + CE fused over row chunks (mrmt3_lmhead_ce_fwd_bwd): dec [rows, d] bf16, w [V, d] bf16 ->
+    (loss_dev[1] f32, dlogits [rows, V] or None).  The f32 logits only ever exist one chunk at a time, in a workspace."""
+    _dev(dec, w, targets)
+    rows, d = dec.shape
+    V = w.shape[0]
+    assert dec.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and dec.stride(1) == 1 and w.stride(1) == 1
+    acc = torch.zeros(2, device=dec.device, dtype=torch.float32)  # [loss, denom]
+    lib = load()
+    _check(lib.mrmt3_ce_count(_p(targets), rows, int(weighted), inst_lo, inst_hi, C.c_void_p(acc.data_ptr() + 4),
+                              _stream()), "ce_count")
+    dl = torch.empty(rows, V, device=dec.device, dtype=grad_dtype) if want_grad else None
+    ws = workspace(min(rows, chunk_rows) * V * 4, dec.device)
+    _check(lib.mrmt3_lmhead_ce_fwd_bwd(_p(dec), dec.stride(0), _p(w), w.stride(0), _p(targets),
+                                       C.c_void_p(acc.data_ptr() + 4), _p(acc), _p(dl), _dt(dl) if dl is not None else F32,
+                                       rows, V, d, int(weighted), inst_lo, inst_hi, grad_scale, _p(ws), ws.numel(),
+                                       chunk_rows, _stream()), "lmhead_ce_fwd_bwd")
     return acc[0:1], dl
 
 

@@ -85,11 +85,10 @@ class Trainer:
         eng, flat = self.engine, self.flat
         eng._stream_ctr = 0                                  # dropout site ids are per-step (step_dev salts them)
         mel = self.mel_from_audio(inputs) if audio else inputs
-        logits, tape = eng.forward(mel, labels, targets_prev, training=True, need_grad=True)
-        B, Ld, V = logits.shape
-        loss, dl = lib.cross_entropy(logits.view(B * Ld, V), labels.reshape(-1), want_grad=True,
-                                     grad_dtype=torch.bfloat16, weighted=self.weighted)
-        del logits
+        dec, tape = eng.forward(mel, labels, targets_prev, training=True, need_grad=True, want_logits=False)
+        # lm_head + CE over row chunks: the f32 logits exist one chunk at a time in a cache-sized workspace
+        loss, dl = lib.lmhead_cross_entropy(dec, eng.W("lm_head"), labels.reshape(-1), want_grad=True,
+                                            grad_dtype=torch.bfloat16, weighted=self.weighted)
         flat.G.zero_()
         self.buckets.reset()
         if cut is None:
@@ -256,7 +255,7 @@ class Trainer:
     def eval_loss(self, inputs, labels, targets_prev=None, audio: bool = False):
         self.model.eval()
         mel = self.mel_from_audio(inputs) if audio else inputs
-        logits, _ = self.engine.forward(mel, labels, targets_prev, training=False, need_grad=False)
-        B, Ld, V = logits.shape
-        loss, _ = lib.cross_entropy(logits.view(B * Ld, V), labels.reshape(-1), want_grad=False, weighted=self.weighted)
+        dec, _ = self.engine.forward(mel, labels, targets_prev, training=False, need_grad=False, want_logits=False)
+        loss, _ = lib.lmhead_cross_entropy(dec, self.engine.W("lm_head"), labels.reshape(-1), want_grad=False,
+                                           weighted=self.weighted)
         return loss

@@ -800,3 +800,30 @@ def test_gemm8_and_tn8_race_screen_bitwise_repeatable_under_load(dev, monkeypatc
             lib.gemm_tn(a, b, out)
             bad += int(not torch.equal(out, first))
         assert bad == 0, (M, N1, N2, bad)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_lmhead_ce_fused_chunks_equal_gemm_then_ce(dev, weighted):
+    """mrmt3_lmhead_ce_fwd_bwd: lm_head + CE over row chunks with the f32 logits only in a chunk-sized
+    workspace == mrmt3_gemm_nt followed by mrmt3_ce_fwd_bwd on the whole [rows, V] tensor: dlogits bit-identical, loss equal
+    up to the order of its float-atomic accumulation; also against the f64 torch loss."""
+    from mrmt3 import lib
+    from mrmt3.synthetic import synth_labels
+    torch.manual_seed(7)
+    rows, d, V = 5 * 1024 + 256, 512, 1536
+    dec = torch.randn(rows, d, device=dev).bfloat16()
+    w = (torch.randn(V, d, device=dev) * 0.05).bfloat16()
+    tg = torch.from_numpy(synth_labels(rows // 256, 256, full=False, seed=3, mean_len=120)).to(dev).reshape(-1)
+    if weighted:
+        tg[::7] = 1200                                      # instrument tokens (weight 3 / count 2)
+    logits = lib.gemm_nt(dec, w, out_dtype=torch.float32)
+    loss_a, dl_a = lib.cross_entropy(logits, tg, weighted=weighted)
+    for chunk in (1024, 4096, 1 << 20):
+        loss_b, dl_b = lib.lmhead_cross_entropy(dec, w, tg, weighted=weighted, chunk_rows=chunk)
+        assert torch.equal(dl_a, dl_b)
+        assert abs(loss_a.item() - loss_b.item()) < 2e-6 * max(1.0, abs(loss_a.item()))
+    loss_c, none = lib.lmhead_cross_entropy(dec, w, tg, want_grad=False, weighted=weighted)
+    assert none is None and abs(loss_c.item() - loss_a.item()) < 2e-6 * max(1.0, abs(loss_a.item()))
+    if not weighted:
+        ref = torch.nn.functional.cross_entropy(logits.double(), tg, ignore_index=-100).item()
+        assert abs(loss_b.item() - ref) < 2e-5
