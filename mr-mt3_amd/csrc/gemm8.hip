@@ -25,6 +25,11 @@
 //     permuted on the LDS-DMA source address, so that a lane's accumulators hold runs of consecutive columns of one
 //     C row and the four lanes of a row write one contiguous 64-byte segment per store instruction: the epilogue
 //     stores straight from registers, 16 bytes per lane, no LDS transposition.
+//   * (tried, not kept: all 160 KiB of LDS — a third B buffer, B requested three K steps ahead, 7 instead of 4 half-tiles
+//     in flight per CU.  Same results, 917 against 945 TF over the step's shapes: the K loop is not waiting for bytes in
+//     flight.  A side lesson of that variant: when the K-step body grew a second lambda, hipcc stopped inlining it, the
+//     accumulators it captures by reference went to scratch memory and the kernel ran 50x slower — if a lambda here is
+//     ever not inlined, force it with __attribute__((always_inline)).)
 //   * N need only be a multiple of 128: the last column tile is shifted left to end at N and masks the columns the
 //     tile before it owns.
 #include <stdlib.h>
