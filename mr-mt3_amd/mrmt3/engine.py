@@ -395,8 +395,9 @@ class Engine:
         dec = torch.cat([labels.new_full((B, 1), start_id), labels[:, :-1]], 1)
         dec = dec.masked_fill(dec == -100, pad_id)
         seg = torch.cat([dec[:, 1:], dec.new_zeros(B, 1)], 1)
-        dummy = dec.new_zeros(1, L)
-        dummy[0, 0] = 1
+        # row 0's memory ids: [1, 0, 0, ...] — built on the device (an indexed host write would be a host-to-device copy,
+        # which a hipGraph capture of the step does not allow)
+        dummy = (torch.arange(L, device=dec.device) == 0).to(dec.dtype).unsqueeze(0)
         return torch.cat([dummy, seg[:-1]], 0).contiguous()
 
     # ---- full forward / backward --------------------------------------------------------------------------

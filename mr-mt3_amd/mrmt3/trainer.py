@@ -141,7 +141,17 @@ class Trainer:
             if seen < self.graph_warmup:
                 self._eager_seen[sig] = seen + 1
                 return self._step_body(inputs, labels, targets_prev, audio)
-            cap = self._capture(sig, inputs, labels, targets_prev, audio)
+            try:
+                cap = self._capture(sig, inputs, labels, targets_prev, audio)
+            except Exception as e:     # noqa: BLE001 — whatever a capture trips over, the eager step is still correct
+                # (nothing executed during the failed capture: the step below is the first to run)
+                import warnings
+                warnings.warn("hipGraph capture of the training step failed (%s: %s); continuing with eager launches"
+                              % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+                self.use_graph = False
+                self.engine._stream_ctr = 0
+                torch.cuda.synchronize()
+                return self._step_body(inputs, labels, targets_prev, audio)
         self.engine.prepare(True)          # weights written through torch since the last step? rebuild the shadows
         cap.inputs.copy_(inputs, non_blocking=True)
         cap.labels.copy_(labels, non_blocking=True)

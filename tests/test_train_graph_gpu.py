@@ -24,6 +24,12 @@ def _model(variant, dev, **cfg_over):
     if variant == "t5":
         from models.t5 import T5ForConditionalGeneration
         return T5ForConditionalGeneration(cfg).load_golden().to(dev)
+    if variant == "v1":
+        from models.t5_segmem import T5SegMem
+        return T5SegMem(cfg, 1, 64).load_golden().to(dev)
+    if variant == "v2":
+        from models.t5_segmem_v2 import T5SegMemV2
+        return T5SegMemV2(cfg, 1, 64).load_golden().to(dev)
     from models.t5_segmem_v2_with_prev import T5SegMemV2WithPrev
     return T5SegMemV2WithPrev(cfg, 1, 64).load_golden().to(dev)
 
@@ -39,14 +45,14 @@ def _batches(dev, n, B=3, L=192, with_prev=False):
     return out
 
 
-@pytest.mark.parametrize("variant", ["t5", "with_prev"])
+@pytest.mark.parametrize("variant", ["t5", "with_prev", "v1", "v2"])
 def test_graph_replay_is_bitwise_the_eager_trajectory(dev, variant):
     """20 optimizer steps, dropout ON, cosine-warmup schedule, three rotating batches: graph trainer == eager trainer
     in every logged loss and in the final weights and AdamW moments, bit for bit."""
     from mrmt3.trainer import Trainer
     from utils import cosine_warmup_lambda
     lam = cosine_warmup_lambda(5, 100, min_lr=1e-4)
-    data = _batches(dev, 3, with_prev=(variant != "t5"))
+    data = _batches(dev, 3, with_prev=(variant == "with_prev"))
     runs = {}
     for use_graph in (False, True):
         m = _model(variant, dev)
@@ -124,3 +130,28 @@ def test_host_issue_time_of_a_replayed_step(dev):
     print("host issue per step: eager %.2f ms, graph %.2f ms" % (1e3 * times[False], 1e3 * times[True]))
     assert times[True] < 3e-3, times
     assert times[True] < 0.4 * times[False], times
+
+
+def test_a_failed_capture_falls_back_to_eager_steps(dev, monkeypatch):
+    """Whatever a capture trips over (an op that is illegal under capture in some configuration), training goes on with
+    eager launches instead of dying: same losses as a trainer that never captured."""
+    import warnings
+    from mrmt3.trainer import Trainer
+    a, t, _ = _batches(dev, 1)[0]
+    ref = Trainer(_model("t5", dev), lr=1e-3, graph=False)
+    want = [float(ref.train_step(a, t, audio=True).item()) for _ in range(5)]
+    tr = Trainer(_model("t5", dev), lr=1e-3, graph=True)
+    real_forward = tr.engine.forward
+    calls = {"n": 0}
+
+    def forward(*args, **kw):
+        calls["n"] += 1
+        if calls["n"] == 3:                        # the third step is the one being captured
+            torch.cuda.synchronize()               # illegal while the stream is capturing
+        return real_forward(*args, **kw)
+    monkeypatch.setattr(tr.engine, "forward", forward)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = [float(tr.train_step(a, t, audio=True).item()) for _ in range(5)]
+    assert any("capture" in str(x.message) for x in w) and not tr.use_graph and not tr.graph_captured
+    assert np.allclose(got, want, rtol=0, atol=2e-6), (got, want)
