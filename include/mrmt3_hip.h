@@ -157,6 +157,15 @@ int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float 
 int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
                     uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 
+/* K2 + K7 in one launch (the feed-forward input projection, models/t5.py T5DenseGatedGeluDense.forward):
+ * h [rows][ldh >= 2 dff] = x [rows][K] . wi [2 dff][K]^T (bf16, kept for the backward) and
+ * g [rows][ldg >= dff] = dropout(gelu_new(h[:, :dff]) * h[:, dff:]).  Bit-identical to mrmt3_gemm_nt followed by
+ * mrmt3_geglu_fwd (which is what runs when the shape is outside the fused kernel's: rows < 4096, dff or K not a
+ * multiple of 128).  bf16 only. */
+int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int ldw, void* h, int ldh, void* g, int ldg,
+                        int rows, int dff, int K, float p_drop, uint64_t seed, const int32_t* step_dev,
+                        uint32_t stream_id, void* stream);
+
 /* ---- K8: embedding gather + sinusoid add (+dropout) and its scatter-add backward ---------------
  * models/t5.py:539-540,596-601 and `_shift_right` (t5.py:148-150).
  * ids [rows] int64.  shift!=0 applies HF _shift_right inside the gather: position t of a

@@ -48,6 +48,11 @@ struct G8Params {
   void* C;
   int lda, ldb, ldc, M, N, K;
   int tiles_n, n_tiles;
+  // EPI = 1 (gated GELU, the wi projection): N = 2 dff, C = h [M][2 dff] as always, C2 = g [M][dff] =
+  // dropout(gelu_new(h0) * h1) computed in the epilogue from the bf16-rounded h (what mrmt3_geglu_fwd reads back)
+  void* C2;
+  int ldc2, dff;
+  DropCfg drop;
   int dbg;             // diagnostics (MRMT3_GEMM8_DBG): 1 no C stores, 2 plain instead of streaming C stores (bf16), 4 every K step re-reads K step 0 (cache-hot),
                        // 8 no fragment reads, 16 loads switched off (zero fill, no traffic)
   int skew_ticks;      // start delay per (slot % 8), in 10-ns ticks of s_memrealtime (see the kernel)
@@ -78,8 +83,9 @@ __device__ __forceinline__ void g8_dma16(__amdgpu_buffer_rsrc_t r, unsigned char
 
 // RT = 16-row tiles per wave (8: 256-row workgroup tile, 4: 128-row).  NST = global stores (and loads, ACCUM) the
 // epilogue of one tile issues per lane: they sit in the vmcnt queue behind the loads the next K step waits for.
-template <typename TOUT, bool ACCUM, int RT>
+template <typename TOUT, bool ACCUM, int RT, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
+  static_assert(EPI == 0 || (sizeof(TOUT) == 2 && !ACCUM), "the GEGLU epilogue writes bf16");
   constexpr int GROUP_ROWS = RT * 16;          // rows of one wave group
   constexpr int BM = 2 * GROUP_ROWS;
   constexpr int NA = RT / 4;                   // LDS-DMA instructions per thread and A half-tile (2 or 1)
@@ -90,6 +96,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = w >> 2, wc = w & 3;
   const int fr = lane & 15, fg = lane >> 4;
+  DropCfg dc = P.drop;
+  if (EPI == 1) DROP_STEP(dc);
 
   // ---- this workgroup's tiles: XCD x (= blockIdx % 8) owns a contiguous range, its workgroups stride through it
   const int nx = (int)gridDim.x >> 3;                       // workgroups per XCD (grid is a multiple of 8)
@@ -114,6 +122,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     const int t = xstart + slot + it * nx;
     const int mt = t / P.tiles_n, nt = t - mt * P.tiles_n;
     m0 = mt * BM;
+    if (EPI == 1) {                                         // a tile = 128 features: their h0 AND h1 columns
+      n0 = nt * 128;
+      cmin = 0;
+      return;
+    }
     n0 = min(nt * 256, P.N - 256);
     cmin = nt * 256;                                        // columns below belong to the tile on the left
   };
@@ -144,10 +157,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     // cost 5.5 us per tile against 11 us for its K loop)
     const int j = (rr >> 4) & 1, ii = rr & 15;
     const int cm = sizeof(TOUT) == 2 ? (ii >> 2) * 8 + j * 4 + (ii & 3) : j * 16 + ii;
-    const int brow = (rr >> 5) * 64 + cm;
+    // EPI 1: the wave's 64 columns are 32 features x (h0 | h1): HB0 = the wi_0 rows of the features, HB1 = their wi_1
+    // rows (dff rows further down), so a lane holds h0 and h1 of the same 8 features
+    const int brow = EPI == 1 ? (rr >> 5) * 32 + cm : (rr >> 5) * 64 + cm;
     voffB[i] = (unsigned)(brow * P.ldb * 2 + sw * 16);
   }
-  const unsigned a1_delta = (unsigned)(RT * 8 * P.lda * 2), b1_delta = (unsigned)(32 * P.ldb * 2);
+  const unsigned a1_delta = (unsigned)(RT * 8 * P.lda * 2);
+  const unsigned b1_delta = EPI == 1 ? (unsigned)(P.dff * P.ldb * 2) : (unsigned)(32 * P.ldb * 2);
   const int piece0 = w * 1024;                              // LDS offset of this wave's piece inside a half-tile
 
   auto load_a = [&](int buf, int half, int soff) {          // half 0: HA0, 1: HA1
@@ -260,6 +276,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   // that are younger than the load they wait for.
   auto store_rows = [&](int i0, int m0, int n0, int cmin, bool count) {
     if (P.dbg & 1) return;
+    if constexpr (EPI == 1) {
+      // gated GELU: three 16-byte stores per row tile (h0, h1, g), rows on fr, 8 features per lane
+      const int f0 = n0 + wc * 32 + fg * 8;
+#pragma unroll
+      for (int ii = 0; ii < RH / 2; ++ii) {
+        const int i = i0 + ii;
+        const int row = m0 + g * GROUP_ROWS + i * 16 + fr;
+        const unsigned h0p[4] = {pack_bf2(acc[i][0][0], acc[i][0][1]), pack_bf2(acc[i][0][2], acc[i][0][3]),
+                                 pack_bf2(acc[i][1][0], acc[i][1][1]), pack_bf2(acc[i][1][2], acc[i][1][3])};
+        const unsigned h1p[4] = {pack_bf2(acc[i][2][0], acc[i][2][1]), pack_bf2(acc[i][2][2], acc[i][2][3]),
+                                 pack_bf2(acc[i][3][0], acc[i][3][1]), pack_bf2(acc[i][3][2], acc[i][3][3])};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a_lo = __uint_as_float(h0p[e] << 16), a_hi = __uint_as_float(h0p[e] & 0xFFFF0000u);
+          const float b_lo = __uint_as_float(h1p[e] << 16), b_hi = __uint_as_float(h1p[e] & 0xFFFF0000u);
+          o[2 * e] = gelu_new_f(a_lo) * b_lo;
+          o[2 * e + 1] = gelu_new_f(a_hi) * b_hi;
+        }
+        if (dc.thresh) {
+          float mk[8];
+          const unsigned long long e8 = ((unsigned long long)row * P.dff + f0) >> 2;
+          drop_mask4(dc, e8, mk);
+          drop_mask4(dc, e8 + 1, mk + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= mk[e];
+        }
+        if (row < P.M) {
+          bf16_t* hp = (bf16_t*)P.C + (size_t)row * P.ldc + f0;
+          __builtin_nontemporal_store((u32x4{h0p[0], h0p[1], h0p[2], h0p[3]}), (u32x4*)hp);
+          __builtin_nontemporal_store((u32x4{h1p[0], h1p[1], h1p[2], h1p[3]}), (u32x4*)(hp + P.dff));
+          __builtin_nontemporal_store((u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])}),
+                                      (u32x4*)((bf16_t*)P.C2 + (size_t)row * P.ldc2 + f0));
+        }
+      }
+      (void)count;
+      return;
+    }
     if (n0 + wc * 64 < cmin) return;                          // columns owned by the tile on the left (wave-uniform)
     TOUT* C = (TOUT*)P.C;
     const bool up = fr >= 8;
@@ -310,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   // counted wait: everything but the YOUNG youngest loads and `extra` batches of interleaved stores has completed.
   // (The immediates must be compile-time constants and a chain of scalar branches per wait is not free: computing the
   // allowance from a running request counter cost 0.45 us per K step.  The five cases below cover the schedule.)
-  constexpr int SQ = ACCUM ? 0 : (RH / 2) * (sizeof(TOUT) == 2 ? 2 : 4);    // stores per lane and batch (0: not counted)
+  constexpr int SQ = ACCUM ? 0 : (RH / 2) * (EPI == 1 ? 3 : (sizeof(TOUT) == 2 ? 2 : 4));   // stores per lane and batch (0: not counted)
   auto wait_young = [&](int extra) {
     if (SQ == 0 || extra == 0) { if (YOUNG == 8) G8_VMCNT(8); else G8_VMCNT(6); return; }
 #define G8_W(k)                                                                               \
@@ -354,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   auto kstep = [&](auto buf_tag, auto first_tag, bool second, bool last) {
     constexpr int buf = decltype(buf_tag)::value;
     constexpr bool first = decltype(first_tag)::value;
-    const bool full = c_m0 + BM <= P.M && c_n0 >= c_cmin && !ACCUM;
+    const bool full = c_m0 + BM <= P.M && c_n0 >= c_cmin && !ACCUM && !(P.dbg & 1);
     const bool pf = p_pending && p_full;                      // the previous tile's batches were issued in full
     const int x4 = (last && full ? 2 : 0) + (first && pf ? 2 : 0);
     // ph1: r0 x c0
@@ -459,4 +513,46 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
   else G8_LAUNCH(float, false);
 #undef G8_LAUNCH
   return 1;
+}
+
+
+// ---- K2+K7 in one launch: h = x . wi^T and g = dropout(gelu_new(h[:, :dff]) * h[:, dff:]) from the same accumulators.
+// Saves the GEGLU kernel's read of h (rows x 2 dff bf16) and one launch per feed-forward block; h is still written
+// (the backward needs it).  Shapes the fused kernel does not take run as the two separate kernels: same results bit for
+// bit either way (the epilogue rounds h to bf16 first and applies the element-wise kernel's arithmetic and mask).
+extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int ldw, void* h, int ldh, void* g, int ldg,
+                                   int rows, int dff, int K, float p_drop, uint64_t seed, const int32_t* step_dev,
+                                   uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(x && wi && h && g, "gemm_nt_geglu: null pointer");
+  MR_CHECK_ARG(rows > 0 && dff > 0 && K > 0 && dff % 8 == 0, "gemm_nt_geglu: bad sizes rows=%d dff=%d K=%d", rows, dff, K);
+  MR_CHECK_ARG(ldh >= 2 * dff && ldg >= dff, "gemm_nt_geglu: ldh >= 2 dff and ldg >= dff");
+  hipStream_t s = (hipStream_t)stream;
+  bool fused = rows >= 4096 && dff % 128 == 0 && K % 128 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0 &&
+               ldg % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wi % 16) == 0 && ((uintptr_t)h % 16) == 0 &&
+               ((uintptr_t)g % 16) == 0 && ((size_t)rows * ldx + K) * 2 < 0x7FFF0000ull &&
+               ((size_t)2 * dff * ldw + K) * 2 < 0x7FFF0000ull;
+  { const char* e = getenv("MRMT3_GEGLU_FUSED"); if (e && e[0] == '0') fused = false; }
+  if (!fused) {
+    int rc = mrmt3_gemm_nt(x, ldx, wi, ldw, h, ldh, rows, 2 * dff, K, MRMT3_BF16, MRMT3_BF16, 0, stream);
+    if (rc != MRMT3_OK) return rc;
+    MR_CHECK_ARG(ldh == 2 * dff && ldg == dff, "gemm_nt_geglu: the unfused path needs dense h and g");
+    return mrmt3_geglu_fwd(h, g, rows, dff, MRMT3_BF16, p_drop, seed, step_dev, stream_id, stream);
+  }
+  G8Params P;
+  P.A = (const bf16_t*)x; P.B = (const bf16_t*)wi; P.C = h; P.C2 = g;
+  P.lda = ldx; P.ldb = ldw; P.ldc = ldh; P.ldc2 = ldg; P.dff = dff;
+  P.M = rows; P.N = 2 * dff; P.K = K;
+  P.drop = make_drop(p_drop, seed, stream_id, step_dev);
+  P.tiles_n = dff / 128;
+  const int cus = g8_cus() & ~7;
+  const int tiles256 = ceil_div(rows, 256) * P.tiles_n;
+  const bool small = tiles256 < cus;
+  P.n_tiles = small ? ceil_div(rows, 128) * P.tiles_n : tiles256;
+  { const char* e = getenv("MRMT3_GEMM8_DBG"); P.dbg = e ? atoi(e) : 0; }
+  P.skew_ticks = 0;
+  int grid = P.n_tiles < cus ? ((P.n_tiles + 7) & ~7) : cus;
+  if (small) hipLaunchKernelGGL((gemm_nt8_kernel<bf16_t, false, 4, 1>), dim3((unsigned)grid), dim3(512), 0, s, P);
+  else hipLaunchKernelGGL((gemm_nt8_kernel<bf16_t, false, 8, 1>), dim3((unsigned)grid), dim3(512), 0, s, P);
+  MR_CHECK_LAUNCH("gemm_nt_geglu");
+  return MRMT3_OK;
 }

@@ -188,9 +188,12 @@ class Engine:
             s_in = sy
             x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.{ff}.layer_norm.weight"), eps, dt,
                                               p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
-            h = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.wi"))
             s_g = self._sid()
-            g = lib.geglu_fwd(h, p=p, seed=self.seed, step=self.step_dev, stream_id=s_g)
+            if xn.dtype == torch.bfloat16:         # K2 + K7 in one launch (same bits as the two kernels)
+                h, g = lib.gemm_nt_geglu(xn, self.W(f"{prefix}.{i}.wi"), p=p, seed=self.seed, step=self.step_dev, stream_id=s_g)
+            else:
+                h = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.wi"))
+                g = lib.geglu_fwd(h, p=p, seed=self.seed, step=self.step_dev, stream_id=s_g)
             y = lib.gemm_nt(g, self.W(f"{prefix}.{i}.wo"), out_dtype=self.y_dtype)
             sy = self._sid()
             if keep:
@@ -330,8 +333,11 @@ class Engine:
                                     want_lo=tape is not None)
         y = lib.gemm_nt(o, self.W(f"{pre}.0.o"), out_dtype=self.y_dtype)
         x1, xn1, rstd1 = lib.add_rmsnorm_fwd(xs, y, self.ln(f"{b}.1.layer_norm.weight"), eps, dt)
-        h = lib.gemm_nt(xn1, self.W(f"{pre}.0.wi"))
-        g = lib.geglu_fwd(h)
+        if xn1.dtype == torch.bfloat16:
+            h, g = lib.gemm_nt_geglu(xn1, self.W(f"{pre}.0.wi"))
+        else:
+            h = lib.gemm_nt(xn1, self.W(f"{pre}.0.wi"))
+            g = lib.geglu_fwd(h)
         y2 = lib.gemm_nt(g, self.W(f"{pre}.0.wo"), out_dtype=self.y_dtype)
         x2, out, rstd2 = lib.add_rmsnorm_fwd(x1, y2, self.ln(f"{pre}.final_layer_norm.weight"), eps, dt)
         if tape is not None:

@@ -42,6 +42,7 @@ _SIGS = {
     "mrmt3_attn_bwd": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci,
                             ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_gemm_nt_geglu": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_bwd_workspace_bytes": (csz, [ci, ci, ci]),
@@ -408,6 +409,19 @@ def geglu_fwd(h, p=0.0, seed=0, stream_id=0, step=None):
     _check(load().mrmt3_geglu_fwd(_p(h), _p(g), rows, two // 2, _dt(h), p, seed, _p(step), stream_id, _stream()),
            "geglu_fwd")
     return g
+
+
+def gemm_nt_geglu(x, wi, p=0.0, seed=0, stream_id=0, step=None):
+    """h = x . wi^T and g = dropout(gelu_new(h0) * h1) in one launch (bf16); returns (h, g), bit-identical to
+    gemm_nt + geglu_fwd."""
+    assert x.dtype == torch.bfloat16 and wi.dtype == torch.bfloat16 and x.stride(-1) == 1 and wi.stride(-1) == 1
+    rows, K = x.shape
+    two = wi.shape[0]
+    h = torch.empty(rows, two, device=x.device, dtype=torch.bfloat16)
+    g = torch.empty(rows, two // 2, device=x.device, dtype=torch.bfloat16)
+    _check(load().mrmt3_gemm_nt_geglu(_p(x), x.stride(0), _p(wi), wi.stride(0), _p(h), two, _p(g), two // 2, rows,
+                                      two // 2, K, p, seed, _p(step), stream_id, _stream()), "gemm_nt_geglu")
+    return h, g
 
 
 def geglu_bwd(h, dg, p=0.0, seed=0, stream_id=0, step=None):

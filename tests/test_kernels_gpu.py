@@ -827,3 +827,45 @@ def test_lmhead_ce_fused_chunks_equal_gemm_then_ce(dev, weighted):
     if not weighted:
         ref = torch.nn.functional.cross_entropy(logits.double(), tg, ignore_index=-100).item()
         assert abs(loss_b.item() - ref) < 2e-5
+
+
+@pytest.mark.gpu
+def test_gemm_nt_geglu_fused_equals_the_two_kernels_bitwise(dev, monkeypatch):
+    """K2 + K7 in one launch (the wi projection with the gated GELU and its dropout in the GEMM epilogue): h and g are
+    bit-identical to mrmt3_gemm_nt followed by mrmt3_geglu_fwd — same bf16 rounding of h before the activation, same
+    counter-based mask (keyed on the flat index of g, salted by the device step) — on 256- and 128-row tiles, ragged
+    row counts and the shapes that fall back to the two kernels; and g matches the f32 formula
+    (models/t5.py T5DenseGatedGeluDense.forward: gelu_new(wi_0 x) * wi_1 x)."""
+    from mrmt3 import lib
+    torch.manual_seed(11)
+    step = torch.tensor([7], device=dev, dtype=torch.int32)
+    for rows, dff, K in ((32768, 1024, 512), (65536 + 200, 1024, 512), (4096, 1024, 512), (8192 + 72, 512, 256),
+                         (1024, 1024, 512), (4096, 320, 512)):
+        x = torch.randn(rows, K, device=dev).bfloat16()
+        wi = (torch.randn(2 * dff, K, device=dev) * 0.06).bfloat16()
+        for p in (0.0, 0.1):
+            monkeypatch.setenv("MRMT3_GEGLU_FUSED", "0")
+            h0, g0 = lib.gemm_nt_geglu(x, wi, p=p, seed=1234, stream_id=5, step=step if p else None)
+            h1 = lib.gemm_nt(x, wi)
+            g1 = lib.geglu_fwd(h1, p=p, seed=1234, stream_id=5, step=step if p else None)
+            assert torch.equal(h0, h1) and torch.equal(g0, g1)
+            monkeypatch.setenv("MRMT3_GEGLU_FUSED", "1")
+            h, g = lib.gemm_nt_geglu(x, wi, p=p, seed=1234, stream_id=5, step=step if p else None)
+            assert torch.equal(h, h0), (rows, dff, K, p, (h.float() - h0.float()).abs().max().item())
+            assert torch.equal(g, g0), (rows, dff, K, p, (g.float() - g0.float()).abs().max().item())
+            if p == 0.0:
+                hf = x.float() @ wi.float().t()
+                ref = torch.nn.functional.gelu(hf[:, :dff], approximate="tanh") * hf[:, dff:]
+                err = (g.float() - ref).abs().max().item()
+                assert err < 2e-2 * ref.abs().max().item() + 1e-3, (rows, dff, err)
+            else:
+                kept = (g != 0).float().mean().item()
+                assert abs(kept - 0.9) < 5e-3
+    # a different step draws a different mask; the same step the same one
+    x = torch.randn(8192, 512, device=dev).bfloat16()
+    wi = (torch.randn(2048, 512, device=dev) * 0.06).bfloat16()
+    ga = lib.gemm_nt_geglu(x, wi, p=0.1, seed=9, stream_id=2, step=step)[1]
+    gb = lib.gemm_nt_geglu(x, wi, p=0.1, seed=9, stream_id=2, step=step)[1]
+    step.add_(1)
+    gc = lib.gemm_nt_geglu(x, wi, p=0.1, seed=9, stream_id=2, step=step)[1]
+    assert torch.equal(ga, gb) and not torch.equal(ga, gc)
