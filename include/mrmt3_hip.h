@@ -46,6 +46,10 @@ extern "C" {
 /* ABI version (major*10000 + minor*100 + patch) and last error text of the calling thread. */
 int mrmt3_version(void);
 const char* mrmt3_last_error(void);
+/* page-locked host memory for tables that reach the device through an async copy (mrmt3_tn_group_run);
+ * NULL on failure.  Allocate outside stream capture. */
+void* mrmt3_host_alloc(size_t bytes);
+void mrmt3_host_free(void* p);
 
 /* ---- K1: log-mel frontend ---------------------------------------------------------------------
  * contrib/spectrograms.py:92-103,128-145 (pad_end, MelSpectrogram(n_fft 2048, hop, power 1,
@@ -97,6 +101,33 @@ int mrmt3_gemm_tn_splits(int M, int N1, int N2);
 int mrmt3_gemm_tn_partial(const void* A, int lda, const void* B, int ldb, int M, int N1, int N2, void* slabs,
                           size_t slab_bytes, void* stream);
 int mrmt3_tn_reduce_sites(const void* sites_dev, int n_sites, int total_blocks, void* stream);
+
+/* Grouped form: the weight gradients of several linear layers (one gradient bucket of the backward, or all of it)
+ * in ONE MFMA launch + ONE reduce.  Launched one by one a gradient is only 2-16 tiles of 256 x 256, so it has to
+ * cut its token rows into 16-32 ranges to occupy the chip and every range leaves a 256-KiB f32 partial tile; together,
+ * the items (gradient, token range, tile) are planned on the host so that they fill whole rounds over the CUs with
+ * 2-8 ranges per gradient.  The caller keeps A (dY), B (X) alive until the run.  mrmt3_tn_group_plan with
+ * table_host == NULL only sizes (info->table_bytes of host+device table, info->slab_bytes of device scratch); with the
+ * buffers it writes the table (pointers baked in: re-plan when an address changes), which the caller copies to the
+ * device; mrmt3_tn_group_run first copies table_host (page-locked, nullable: table_dev already holds it) to table_dev
+ * on `stream` — a memcpy node when the stream is capturing: the replays re-send the same bytes, so table_host must
+ * outlive the graph — and launches from the device copy.  Per-element summation order is fixed by the plan
+ * (bitwise reproducible for the same plan).  Shapes: mrmt3_tn_group_ok (M >= 1024, N1 % 128 == 0, N2 % 64 == 0,
+ * both >= 256, 16-byte aligned rows); everything else goes through mrmt3_gemm_tn. */
+typedef struct {
+  const void* A;       /* dY [M][lda] bf16 */
+  const void* B;       /* X  [M][ldb] bf16 */
+  float* C;            /* dW [N1][ldc] f32 */
+  int32_t lda, ldb, ldc, M, N1, N2, accumulate, pad;
+} mrmt3_tn_gsite;
+typedef struct {
+  int32_t n_ctas, n_items, n_rtiles, rounds;
+  uint64_t rtile_offset, table_bytes, slab_bytes;
+} mrmt3_tn_group_info;
+int mrmt3_tn_group_ok(int M, int N1, int N2, int lda, int ldb, int ldc);
+int mrmt3_tn_group_plan(const mrmt3_tn_gsite* sites, int n_sites, void* slab_dev, void* table_host, size_t table_cap,
+                        mrmt3_tn_group_info* info);
+int mrmt3_tn_group_run(void* table_dev, const void* table_host, const mrmt3_tn_group_info* info, void* stream);
 
 /* ---- K3: T5LayerNorm (RMS norm) fused with the residual add and dropout that precede it --------
  * HF T5LayerNorm + `hidden + dropout(sublayer_out)` (T5LayerSelfAttention/CrossAttention/FF), and

@@ -14,3 +14,18 @@ void mrmt3_set_error(const char* fmt, ...) {
 
 extern "C" int mrmt3_version(void) { return 100; /* 0.1.0 */ }
 extern "C" const char* mrmt3_last_error(void) { return g_err; }
+
+// Page-locked host memory for tables the device reads through an async copy (the grouped weight-gradient plan): owned by
+// the caller, released with mrmt3_host_free.  Not to be called while a stream of this thread is capturing.
+extern "C" void* mrmt3_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    mrmt3_set_error("host_alloc: hipHostMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void mrmt3_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}

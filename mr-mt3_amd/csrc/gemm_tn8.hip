@@ -15,6 +15,10 @@
 //   * ragged N1 / N2 (384, 768, 1152): the last tile is shifted to end at N and stores only what the tile before it
 //     does not own.
 #include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -30,6 +34,27 @@ struct T8Params {
   int lda, ldb, M, N1, N2;
   int tiles_n2, n_tiles, n_splits, rows_per_split;
 };
+// One unit of work: a 256 x 256 tile of one weight gradient over one range of token rows.  Element (n1, n2) of the
+// partial sum goes to out[n1 * ldo + n2] (n1, n2 are the gradient's own indices: `out` is pre-offset by the planner).
+struct T8Item {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* out;
+  int lda, ldb, ldo;
+  int M, N1, N2;       // bounds of the operands (rows past M read as zeros)
+  int a0, b0;          // tile origin (a shifted last tile starts at N - 256) ...
+  int rmin, cmin;      // ... and the first n1 / n2 it owns
+  int row0, nk;        // token range: rows row0 .. row0 + 64 nk (nk even)
+  int pad;
+};
+static_assert(sizeof(T8Item) == 80, "item layout (the planner writes these records on the host)");
+// One gradient tile of a grouped launch: C[owned part of the tile] (+)= sum of its n_part partial tiles, in order.
+struct T8RTile {
+  const float* slab;   // n_part consecutive [256][256] f32 partial tiles
+  float* C;            // the gradient [N1][ldc]
+  int ldc, a0, b0, rmin, cmin, n_part, accumulate, pad;
+};
+static_assert(sizeof(T8RTile) == 48, "reduce record layout");
 
 __device__ __forceinline__ void t8_dma16(__amdgpu_buffer_rsrc_t r, unsigned char* dst, unsigned voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
@@ -48,26 +73,14 @@ __device__ __forceinline__ bf16x8 t8_frag(unsigned addr) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(T8Params P) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * T8_BUF];
+__device__ __forceinline__ void t8_run_item(const T8Item& P, unsigned char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = w >> 2, wc = w & 3;
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
-
-  // work item: all tiles of one token range run on one XCD (they share the range's rows of dY and X in its L2)
-  int tile, split;
-  {
-    const int n = (int)gridDim.x, per = n >> 3;
-    const int wi = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (wi >= P.n_tiles * P.n_splits) return;
-    split = wi / P.n_tiles;
-    tile = wi - split * P.n_tiles;
-  }
-  const int t1 = tile / P.tiles_n2, t2 = tile - t1 * P.tiles_n2;
-  const int a0 = min(t1 * 256, P.N1 - 256), b0 = min(t2 * 256, P.N2 - 256);
-  const int rmin = t1 * 256, cmin = t2 * 256;             // rows / columns below belong to the neighbouring tile
-  const int nk = P.rows_per_split >> 6;                    // even (rows_per_split is a multiple of 128)
+  const int a0 = P.a0, b0 = P.b0;
+  const int rmin = P.rmin, cmin = P.cmin;                  // rows / columns below belong to the neighbouring tile
+  const int nk = P.nk;                                     // even
 
   const __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (int)(((size_t)(P.M - 1) * P.lda + P.N1) * 2), 0x00020000);
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(T8Params P) {
     for (int i = 0; i < 2; ++i) t8_dma16(rb, base + i * 8192, voffB[i] + (half ? 64u : 0u), soff);
   };
   int l_k = 0;
-  int l_sa = (split * P.rows_per_split * P.lda + a0) * 2, l_sb = (split * P.rows_per_split * P.ldb + b0) * 2;
+  int l_sa = (P.row0 * P.lda + a0) * 2, l_sb = (P.row0 * P.ldb + b0) * 2;
   const int step_a = 64 * P.lda * 2, step_b = 64 * P.ldb * 2;
   auto cursor_next = [&]() {
     ++l_k;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(T8Params P) {
   // ---- epilogue: lane holds slab[n1 = row tile i, row fr][n2 = 16 ct + 4 fg + r].  The lanes of rows r and r + 8
   // exchange halves (DPP row rotate) so that a store instruction writes 8 rows x 128 contiguous bytes.
   if (b0 + wc * 64 < cmin || a0 + g * 128 < rmin) return;    // owned by the neighbouring tile (wave-uniform)
-  float* out = P.slab + (size_t)split * P.N1 * P.N2;
+  float* out = P.out;
   const bool up = fr >= 8;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -218,10 +231,69 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(T8Params P) {
         recv[e] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send[e]), 0x128, 0xf, 0xf, false));
       const f32x4 v1 = up ? recv : lo, v2 = up ? hi : recv;
       float* p = out + b0 + wc * 64 + cp * 32 + (up ? 16 : 0) + fg * 4;
-      __builtin_nontemporal_store(v1, (f32x4*)(p + (size_t)row1 * P.N2));
-      __builtin_nontemporal_store(v2, (f32x4*)(p + (size_t)row2 * P.N2));
+      __builtin_nontemporal_store(v1, (f32x4*)(p + (size_t)row1 * P.ldo));
+      __builtin_nontemporal_store(v2, (f32x4*)(p + (size_t)row2 * P.ldo));
     }
   }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(T8Params P) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * T8_BUF];
+  // work item: all tiles of one token range run on one XCD (they share the range's rows of dY and X in its L2)
+  const int n = (int)gridDim.x, per = n >> 3;
+  const int wi = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (wi >= P.n_tiles * P.n_splits) return;
+  const int split = wi / P.n_tiles, tile = wi - split * P.n_tiles;
+  const int t1 = tile / P.tiles_n2, t2 = tile - t1 * P.tiles_n2;
+  T8Item I;
+  I.A = P.A; I.B = P.B; I.out = P.slab + (size_t)split * P.N1 * P.N2;
+  I.lda = P.lda; I.ldb = P.ldb; I.ldo = P.N2; I.M = P.M; I.N1 = P.N1; I.N2 = P.N2;
+  I.a0 = min(t1 * 256, P.N1 - 256); I.b0 = min(t2 * 256, P.N2 - 256);
+  I.rmin = t1 * 256; I.cmin = t2 * 256;
+  I.row0 = split * P.rows_per_split; I.nk = P.rows_per_split >> 6;     // (rows_per_split is a multiple of 128)
+  I.pad = 0;
+  t8_run_item(I, lds);
+}
+
+// ---- grouped form: the weight gradients of SEVERAL linear layers in one launch ---------------------------------------
+// A training step has 45-50 weight gradients; launched one by one, each has to cut its token rows into 16-32 ranges to
+// occupy 256 CUs (a gradient is only 2-16 tiles), so every tile is written as 16-32 f32 partial tiles and read back by
+// the reduce: 3 GB each way per step, and 16-64 K steps behind every 256-KiB epilogue.  The backward keeps the operands
+// of a whole gradient bucket alive instead (memory is not the constraint on this part) and launches its gradients
+// together: items (gradient, token range, tile) of nearly equal length, planned on the host (mrmt3_tn_group_plan) so that
+// the item count is a whole number of rounds over the CUs — 2-8 partial tiles per gradient tile, 100-400 K steps per item.
+// Workgroup l (logical index: XCD-major, so that the tiles of one token range share an L2) runs items l, l + G, ...
+__global__ __launch_bounds__(512, 2) void gemm_tn8_group_kernel(const T8Item* __restrict__ items, int n_items) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * T8_BUF];
+  const int n = (int)gridDim.x, per = n >> 3;
+  const int l = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  for (int j = l; j < n_items; j += n) {
+    const T8Item I = items[j];
+    t8_run_item(I, lds);
+  }
+}
+
+// sum of the partial tiles of the grouped launch: 64 workgroups per gradient tile, fixed order (bitwise reproducible)
+__global__ __launch_bounds__(256) void tn8_group_reduce_kernel(const T8RTile* __restrict__ tiles) {
+  const T8RTile t = tiles[blockIdx.x >> 6];
+  const int idx = ((int)(blockIdx.x & 63) << 8) + (int)threadIdx.x;    // float4 index inside the tile
+  const int r = idx >> 6, c = (idx & 63) << 2;
+  const int n1 = t.a0 + r, n2 = t.b0 + c;
+  if (n1 < t.rmin || n2 < t.cmin) return;
+  const float* __restrict__ sp = t.slab + (size_t)r * 256 + c;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 4 <= t.n_part; k += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load((const f32x4*)(sp + (size_t)(k + u) * 65536));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u];
+  }
+  for (; k < t.n_part; ++k) s += __builtin_nontemporal_load((const f32x4*)(sp + (size_t)k * 65536));
+  float* p = t.C + (size_t)n1 * t.ldc + n2;
+  if (t.accumulate) s += *(const f32x4*)p;
+  *(f32x4*)p = s;
 }
 
 // Plan shared with gemm.hip's mrmt3_gemm_tn*: returns 1 when this kernel takes the shape.
@@ -261,4 +333,148 @@ int mrmt3_tn8_launch(const void* A, int lda, const void* B, int ldb, float* slab
   P.tiles_n2 = ceil_div(N2, 256); P.n_tiles = tiles; P.n_splits = splits; P.rows_per_split = rps;
   hipLaunchKernelGGL(gemm_tn8_kernel, dim3((unsigned)((tiles * splits + 7) & ~7)), dim3(512), 0, s, P);
   return 0;
+}
+
+
+// ---- grouped launch: host planner -----------------------------------------------------------------------------------
+static int t8_cus() {
+  static int hw = 0;
+  if (hw == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) hw = prop.multiProcessorCount;
+    if (hw <= 0) hw = 256;
+  }
+  int cus = hw;
+  { const char* e = getenv("MRMT3_TN_GROUP_CTAS"); if (e && atoi(e) >= 8) cus = atoi(e); }   // tests / tuning
+  return cus & ~7;
+}
+
+extern "C" int mrmt3_tn_group_ok(int M, int N1, int N2, int lda, int ldb, int ldc) {
+  return M >= 1024 && N1 >= 256 && N2 >= 256 && N1 % 128 == 0 && N2 % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+         ldc % 4 == 0 && ((size_t)M + 128) * (size_t)(lda > ldb ? lda : ldb) * 2 < 0x7FFF0000ull;
+}
+
+// Units of 128 token rows (two K steps).  For every candidate item length the gradients are cut into R_s token ranges
+// of equal length, the items dealt round-robin over the workgroups in launch order (longest first), and the cost is the
+// busiest workgroup's units (+ a prologue/epilogue allowance per item) plus the partial tiles' traffic.
+extern "C" int mrmt3_tn_group_plan(const mrmt3_tn_gsite* sites, int n_sites, void* slab_dev, void* table_host,
+                                   size_t table_cap, mrmt3_tn_group_info* info) {
+  MR_CHECK_ARG(sites && n_sites > 0 && info, "tn_group_plan: bad arguments");
+  const int G = t8_cus();
+  struct SP { int T1, T2, T, U, R, len; };
+  std::vector<SP> sp(n_sites);
+  double W = 0;
+  for (int s = 0; s < n_sites; ++s) {
+    const mrmt3_tn_gsite& S = sites[s];
+    MR_CHECK_ARG(S.A && S.B && S.C && mrmt3_tn_group_ok(S.M, S.N1, S.N2, S.lda, S.ldb, S.ldc),
+                 "tn_group_plan: site %d (M=%d N1=%d N2=%d) is outside the grouped kernel's shapes", s, S.M, S.N1, S.N2);
+    sp[s].T1 = ceil_div(S.N1, 256); sp[s].T2 = ceil_div(S.N2, 256); sp[s].T = sp[s].T1 * sp[s].T2;
+    sp[s].U = ceil_div(S.M, 128);
+    W += (double)sp[s].T * sp[s].U;
+  }
+  const double OVH = 2.0, US_PER_UNIT = 2.9, US_PER_ITEM = 0.12;
+  double best = 1e30;
+  std::vector<int> bestR(n_sites, 1), load(G);
+  for (int k = 1; k <= 8; ++k)
+    for (int fi = 0; fi <= 12; ++fi) {
+      const double Lt = W / ((double)k * G) * (0.76 + 0.045 * fi);
+      if (Lt < 8.0 && !(k == 1 && fi == 12)) continue;       // at least 1024 rows behind a 256 KiB partial tile
+      std::vector<int> R(n_sites), len(n_sites), order(n_sites);
+      for (int s = 0; s < n_sites; ++s) {
+        int r = (int)((double)sp[s].U / (Lt < 8.0 ? 8.0 : Lt) + 0.5);
+        const int rmax = sp[s].U / 8 > 0 ? sp[s].U / 8 : 1;
+        r = r < 1 ? 1 : (r > rmax ? rmax : r);
+        len[s] = ceil_div(sp[s].U, r);
+        R[s] = ceil_div(sp[s].U, len[s]);
+        order[s] = s;
+      }
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+      std::fill(load.begin(), load.end(), 0);
+      long j = 0;
+      for (int oi = 0; oi < n_sites; ++oi) {
+        const int s = order[oi];
+        for (int r = 0; r < R[s]; ++r) {
+          const int bl = std::min(len[s], sp[s].U - r * len[s]);
+          for (int t = 0; t < sp[s].T; ++t, ++j) load[j % G] += bl + (int)OVH;
+        }
+      }
+      const double cost = *std::max_element(load.begin(), load.end()) * US_PER_UNIT + (double)j * US_PER_ITEM;
+      if (cost < best) { best = cost; bestR = R; }
+    }
+  // ---- emit
+  std::vector<int> order(n_sites), len(n_sites);
+  long n_items = 0, n_rt = 0;
+  for (int s = 0; s < n_sites; ++s) {
+    sp[s].R = bestR[s];
+    len[s] = sp[s].len = ceil_div(sp[s].U, sp[s].R);
+    order[s] = s;
+    n_items += (long)sp[s].T * sp[s].R;
+    n_rt += sp[s].T;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+  const size_t items_bytes = ((size_t)n_items * sizeof(T8Item) + 63) & ~(size_t)63;
+  info->n_ctas = G;
+  info->n_items = (int)n_items;
+  info->n_rtiles = (int)n_rt;
+  info->rounds = (int)((n_items + G - 1) / G);
+  info->rtile_offset = (uint64_t)items_bytes;
+  info->table_bytes = (uint64_t)(items_bytes + (size_t)n_rt * sizeof(T8RTile));
+  info->slab_bytes = (uint64_t)n_items * 65536ull * sizeof(float);
+  if (!table_host) return MRMT3_OK;                          // sizing pass
+  MR_CHECK_ARG(slab_dev && table_cap >= info->table_bytes, "tn_group_plan: table buffer too small or no slab buffer");
+  T8Item* items = (T8Item*)table_host;
+  T8RTile* rts = (T8RTile*)((char*)table_host + items_bytes);
+  memset(table_host, 0, (size_t)info->table_bytes);
+  float* slab = (float*)slab_dev;
+  long j = 0, slab_idx = 0, rt = 0;
+  for (int oi = 0; oi < n_sites; ++oi) {
+    const int s = order[oi];
+    const mrmt3_tn_gsite& S = sites[s];
+    const SP& p = sp[s];
+    const long base = slab_idx;                              // partial tile (t, r) of this gradient: base + t * R + r
+    for (int r = 0; r < p.R; ++r) {
+      const int bl = std::min(p.len, p.U - r * p.len);
+      for (int t = 0; t < p.T; ++t, ++j) {
+        const int t1 = t / p.T2, t2 = t - t1 * p.T2;
+        T8Item& I = items[j];
+        I.A = (const bf16_t*)S.A; I.B = (const bf16_t*)S.B;
+        I.lda = S.lda; I.ldb = S.ldb; I.ldo = 256; I.M = S.M; I.N1 = S.N1; I.N2 = S.N2;
+        I.a0 = std::min(t1 * 256, S.N1 - 256); I.b0 = std::min(t2 * 256, S.N2 - 256);
+        I.rmin = t1 * 256; I.cmin = t2 * 256;
+        I.row0 = r * p.len * 128; I.nk = bl * 2;
+        I.out = slab + (base + (long)t * p.R + r) * 65536 - ((long)I.a0 * 256 + I.b0);
+      }
+    }
+    for (int t = 0; t < p.T; ++t, ++rt) {
+      const int t1 = t / p.T2, t2 = t - t1 * p.T2;
+      T8RTile& Q = rts[rt];
+      Q.slab = slab + (base + (long)t * p.R) * 65536;
+      Q.C = S.C; Q.ldc = S.ldc;
+      Q.a0 = std::min(t1 * 256, S.N1 - 256); Q.b0 = std::min(t2 * 256, S.N2 - 256);
+      Q.rmin = t1 * 256; Q.cmin = t2 * 256;
+      Q.n_part = p.R; Q.accumulate = S.accumulate;
+    }
+    slab_idx += (long)p.T * p.R;
+  }
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_tn_group_run(void* table_dev, const void* table_host, const mrmt3_tn_group_info* info, void* stream) {
+  MR_CHECK_ARG(table_dev && info && info->n_items > 0 && info->n_rtiles > 0 && info->n_ctas >= 8, "tn_group_run: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (table_host) {
+    const hipError_t e = hipMemcpyAsync(table_dev, table_host, (size_t)info->table_bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      mrmt3_set_error("tn_group_run: table copy failed: %s", hipGetErrorString(e));
+      return MRMT3_ERR_HIP;
+    }
+  }
+  hipLaunchKernelGGL(gemm_tn8_group_kernel, dim3((unsigned)info->n_ctas), dim3(512), 0, s, (const T8Item*)table_dev,
+                     info->n_items);
+  MR_CHECK_LAUNCH("tn_group_run");
+  hipLaunchKernelGGL(tn8_group_reduce_kernel, dim3((unsigned)info->n_rtiles * 64u), dim3(256), 0, s,
+                     (const T8RTile*)((const char*)table_dev + info->rtile_offset));
+  MR_CHECK_LAUNCH("tn_group_run reduce");
+  return MRMT3_OK;
 }

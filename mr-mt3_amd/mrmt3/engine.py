@@ -75,6 +75,9 @@ class Engine:
         self.norm_dw = lib.NormDwBatch() if os.environ.get("MRMT3_NORM_DW_BATCH", "1") != "0" else None
         # split-K slabs of the weight-gradient GEMMs: kept per site and summed in one launch (lib.TnBatch)
         self.tn_batch = lib.TnBatch() if os.environ.get("MRMT3_TN_BATCH", "1") != "0" else None
+        # ... and, for every shape the grouped kernel takes, the GEMMs themselves are deferred to the next join_wgrad():
+        # one launch for the weight gradients of a whole gradient bucket (lib.TnGroup)
+        self.tn_group = lib.TnGroup() if os.environ.get("MRMT3_TN_GROUP", "1") != "0" else None
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def pos(self, device):
@@ -104,6 +107,8 @@ class Engine:
         host (45 calls per step): events come from a small ring, the kernel is launched on the side stream
         directly, and the operands are kept alive by reference until the next join instead of
         `record_stream` bookkeeping."""
+        if self.tn_group is not None and self.tn_group.ok(a, b, out):
+            return self.tn_group.add(a, b, out, accumulate=True)
         if not self.overlap_wgrad:
             return lib.gemm_tn(a, b, out, accumulate=True, defer=self.tn_batch)
         side = self.side_stream()
@@ -136,6 +141,8 @@ class Engine:
             self._held.clear()
         if self.tn_batch is not None:
             self.tn_batch.flush()        # behind the GEMMs that produced the slabs (same stream, or joined above)
+        if self.tn_group is not None:
+            self.tn_group.flush()        # the deferred weight gradients: their operands were produced on this stream
 
     def prepare(self, training: bool):
         if self.dt == torch.bfloat16:

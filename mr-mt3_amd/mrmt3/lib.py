@@ -43,6 +43,11 @@ _SIGS = {
                             ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_gemm_nt_geglu": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_tn_group_ok": (ci, [ci, ci, ci, ci, ci, ci]),
+    "mrmt3_tn_group_plan": (ci, [vp, ci, vp, vp, C.c_size_t, vp]),
+    "mrmt3_tn_group_run": (ci, [vp, vp, vp, vp]),
+    "mrmt3_host_alloc": (vp, [C.c_size_t]),
+    "mrmt3_host_free": (None, [vp]),
     "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_bwd_workspace_bytes": (csz, [ci, ci, ci]),
@@ -266,6 +271,119 @@ class TnBatch:
             self._tables[keys] = tab
         _check(load().mrmt3_tn_reduce_sites(_p(tab[0]), tab[1], tab[2], _stream()), "tn_reduce_sites")
         self._queue.clear()
+
+
+class _TnGSite(C.Structure):          # = mrmt3_tn_gsite
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("lda", "ldb", "ldc", "M", "N1", "N2", "accumulate", "pad")]
+
+
+class _TnGInfo(C.Structure):          # = mrmt3_tn_group_info
+    _fields_ = [(n, C.c_int32) for n in ("n_ctas", "n_items", "n_rtiles", "rounds")] + \
+               [(n, C.c_uint64) for n in ("rtile_offset", "table_bytes", "slab_bytes")]
+
+
+class _PinnedTable:
+    """Page-locked host bytes from the library's own allocator (torch's pinned-memory cache polls events when it
+    allocates, which is illegal while a stream of the thread is capturing)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = load().mrmt3_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise RuntimeError("mrmt3_host_alloc failed: " + load().mrmt3_last_error().decode())
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().mrmt3_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = None
+
+
+class TnGroup:
+    """The weight-gradient GEMMs of a whole gradient bucket (or of the whole backward) in ONE MFMA launch + ONE reduce
+    (mrmt3_tn_group_plan / mrmt3_tn_group_run).  `add()` only records the operands (and keeps them alive); `flush()`
+    plans the items on the host — cached per set of (addresses, shapes) — and launches on the current stream; the table
+    reaches the device through an async copy from page-locked memory (a memcpy node when the step is being captured:
+    the replays re-send the same bytes).  Gradients are complete after flush().
+
+    Nothing is allocated from the host while a stream is capturing: every eager plan leaves a spare page-locked table
+    of its size behind, which the capture of the same step (same shapes, new addresses) picks up."""
+
+    def __init__(self):
+        self._sites = []
+        self._plans = {}          # key -> dict(host, table, info, flops, slab, captured)
+        self._spare = []          # page-locked tables ready for a plan made under capture
+        self._slab = None
+        self.last_info = None
+
+    @staticmethod
+    def ok(a, b, out):
+        return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and out.dtype == torch.float32 and
+                a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and
+                bool(load().mrmt3_tn_group_ok(a.shape[0], a.shape[1], b.shape[1], a.stride(0), b.stride(0), out.stride(0))))
+
+    def add(self, a, b, out, accumulate=True):
+        assert a.shape[0] == b.shape[0] and tuple(out.shape) == (a.shape[1], b.shape[1])
+        self._sites.append((a, b, out, int(bool(accumulate))))
+
+    def __len__(self):
+        return len(self._sites)
+
+    def _host_table(self, nbytes, capturing):
+        fit = [i for i, h in enumerate(self._spare) if h.nbytes >= nbytes]
+        if fit:
+            return self._spare.pop(min(fit, key=lambda i: self._spare[i].nbytes))
+        if capturing:
+            raise RuntimeError("TnGroup: no page-locked table of %d bytes was prepared before the capture "
+                               "(run the step eagerly once with the same shapes first)" % nbytes)
+        return _PinnedTable(nbytes)
+
+    def flush(self):
+        if not self._sites:
+            return
+        L = load()
+        dev = self._sites[0][0].device
+        key = tuple((a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), o.data_ptr(), o.stride(0), a.shape[0],
+                     a.shape[1], b.shape[1], acc) for a, b, o, acc in self._sites)
+        ent = self._plans.get(key)
+        if ent is not None and ent["slab"] is not self._slab:
+            ent = None
+        if ent is None:
+            capturing = torch.cuda.is_current_stream_capturing()
+            n = len(self._sites)
+            arr = (_TnGSite * n)()
+            flops = 0.0
+            for i, (a, b, o, acc) in enumerate(self._sites):
+                arr[i] = _TnGSite(a.data_ptr(), b.data_ptr(), o.data_ptr(), a.stride(0), b.stride(0), o.stride(0),
+                                  a.shape[0], a.shape[1], b.shape[1], acc, 0)
+                flops += 2.0 * a.shape[0] * a.shape[1] * b.shape[1]
+            info = _TnGInfo()
+            _check(L.mrmt3_tn_group_plan(arr, n, None, None, 0, C.byref(info)), "tn_group_plan (sizing)")
+            if self._slab is None or self._slab.numel() < info.slab_bytes:
+                self._slab = None
+                self._slab = torch.empty(int(info.slab_bytes), device=dev, dtype=torch.uint8)
+            host = self._host_table(int(info.table_bytes), capturing)
+            _check(L.mrmt3_tn_group_plan(arr, n, _p(self._slab), C.c_void_p(host.ptr), host.nbytes, C.byref(info)),
+                   "tn_group_plan")
+            table = torch.empty(int(info.table_bytes), device=dev, dtype=torch.uint8)
+            ent = dict(host=host, table=table, info=info, flops=flops, slab=self._slab, captured=capturing)
+            if not capturing:
+                if not any(h.nbytes >= host.nbytes for h in self._spare):
+                    self._spare.append(_PinnedTable(host.nbytes))
+                eager = [k for k, e in self._plans.items() if not e["captured"]]
+                if len(eager) >= 128:                          # eager address churn (steady state reuses addresses)
+                    torch.cuda.current_stream().synchronize()  # their table copies have been consumed
+                    for k in eager:
+                        del self._plans[k]
+            self._plans[key] = ent
+        with _Timed("gemm_tn_bf16", ent["flops"], "FLOP"):
+            _check(L.mrmt3_tn_group_run(_p(ent["table"]), C.c_void_p(ent["host"].ptr), C.byref(ent["info"]), _stream()),
+                   "tn_group_run")
+        self.last_info = ent["info"]
+        self._sites.clear()
 
 
 def gemm_tn(a, b, out, accumulate=False, stream=None, defer=None):

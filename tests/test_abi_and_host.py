@@ -95,7 +95,8 @@ def test_every_binding_the_host_code_calls_exists():
             used |= set(re.findall(r"\blib\.([A-Za-z_][A-Za-z0-9_]*)", f.read()))
     missing = sorted(n for n in used if not hasattr(lib, n))
     assert not missing, missing
-    assert {"gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "add_rmsnorm_bwd", "embed_bwd", "cross_entropy"} <= used
+    assert {"gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "add_rmsnorm_bwd", "embed_bwd", "lmhead_cross_entropy",
+            "gemm_nt_geglu", "TnGroup"} <= used
 
 
 def test_master_version_sees_writes_through_reparented_parameters():
@@ -121,3 +122,61 @@ def test_master_version_sees_writes_through_reparented_parameters():
     assert m.flat.master_version() != v1
     assert torch.equal(m.flat.master("lm_head.weight"), other["lm_head.weight"])
     del p_ver
+
+
+def test_grouped_weight_gradient_plan_covers_every_tile_once():
+    """mrmt3_tn_group_plan is host code: for the weight gradients of a decoder + encoder gradient bucket, every
+    (gradient, 256 x 256 tile) is covered by token ranges that partition [0, M) in units of 128 rows, each item owns
+    its own 256-KiB partial tile inside the scratch buffer, the reduce records name exactly those partial tiles, and
+    the busiest workgroup carries at most 15 % more K steps than the average (the planner's whole purpose)."""
+    import ctypes as C
+    import numpy as np
+    from mrmt3 import lib as L
+    lib = L.load()
+    shapes = [(65536, 512, 1024), (65536, 2048, 512), (65536, 512, 384), (65536, 384, 512), (16384, 768, 512),
+              (65536, 1152, 512), (16384, 2048, 512), (16384 + 72, 1152, 512), (4096, 1536, 512)] * 2
+    arr = (L._TnGSite * len(shapes))()
+    for i, (M, N1, N2) in enumerate(shapes):
+        arr[i] = L._TnGSite(0x100000 * (i + 1), 0x200000 * (i + 1), 0x7000000 + 0x100000 * i, N1, N2, N2, M, N1, N2, 1, 0)
+    info = L._TnGInfo()
+    assert lib.mrmt3_tn_group_plan(arr, len(shapes), None, None, 0, C.byref(info)) == 0
+    host = np.zeros(info.table_bytes, np.uint8)
+    slab0 = 0x40000000
+    assert lib.mrmt3_tn_group_plan(arr, len(shapes), C.c_void_p(slab0), C.c_void_p(host.ctypes.data), host.size, C.byref(info)) == 0
+    item_t = np.dtype([("A", "<u8"), ("B", "<u8"), ("out", "<u8"), ("lda", "<i4"), ("ldb", "<i4"), ("ldo", "<i4"),
+                       ("M", "<i4"), ("N1", "<i4"), ("N2", "<i4"), ("a0", "<i4"), ("b0", "<i4"), ("rmin", "<i4"),
+                       ("cmin", "<i4"), ("row0", "<i4"), ("nk", "<i4"), ("pad", "<i4"), ("pad2", "<i4")])
+    rt_t = np.dtype([("slab", "<u8"), ("C", "<u8"), ("ldc", "<i4"), ("a0", "<i4"), ("b0", "<i4"), ("rmin", "<i4"),
+                     ("cmin", "<i4"), ("n_part", "<i4"), ("acc", "<i4"), ("pad", "<i4")])
+    assert item_t.itemsize == 80 and rt_t.itemsize == 48
+    items = np.frombuffer(host[:info.n_items * 80].tobytes(), dtype=item_t)
+    rts = np.frombuffer(host[info.rtile_offset:info.rtile_offset + info.n_rtiles * 48].tobytes(), dtype=rt_t)
+    assert info.n_rtiles == sum(-(-n1 // 256) * -(-n2 // 256) for _, n1, n2 in shapes)
+    cover, slabs = {}, set()
+    for it in items:
+        key = (int(it["A"]), int(it["a0"]), int(it["b0"]))
+        cover.setdefault(key, []).append((int(it["row0"]), int(it["nk"]) * 64))
+        tile_slab = int(it["out"]) + 4 * (int(it["a0"]) * 256 + int(it["b0"]))       # undo the pre-offset
+        assert tile_slab >= slab0 and (tile_slab - slab0) % (256 * 1024) == 0 and tile_slab + 256 * 1024 <= slab0 + info.slab_bytes
+        assert tile_slab not in slabs
+        slabs.add(tile_slab)
+        assert it["nk"] % 2 == 0 and it["ldo"] == 256 and it["row0"] % 128 == 0
+        assert it["rmin"] - it["a0"] in (0, 128) and it["cmin"] - it["b0"] in (0, 128)
+    assert len(cover) == info.n_rtiles
+    Ms = {0x100000 * (i + 1): M for i, (M, _, _) in enumerate(shapes)}
+    for (A, a0, b0), ranges in cover.items():
+        ranges.sort()
+        pos = 0
+        for r0, n in ranges:
+            assert r0 == pos
+            pos += n
+        assert Ms[A] <= pos < Ms[A] + 128
+    listed = set()
+    for rt in rts:
+        for p in range(int(rt["n_part"])):
+            listed.add(int(rt["slab"]) + p * 256 * 1024)
+    assert listed == slabs
+    load = np.zeros(info.n_ctas)
+    for j, it in enumerate(items):
+        load[j % info.n_ctas] += it["nk"]
+    assert load.max() <= 1.15 * load.mean(), (load.max(), load.mean())

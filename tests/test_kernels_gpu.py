@@ -869,3 +869,60 @@ def test_gemm_nt_geglu_fused_equals_the_two_kernels_bitwise(dev, monkeypatch):
     step.add_(1)
     gc = lib.gemm_nt_geglu(x, wi, p=0.1, seed=9, stream_id=2, step=step)[1]
     assert torch.equal(ga, gb) and not torch.equal(ga, gc)
+
+
+@pytest.mark.gpu
+def test_grouped_weight_gradients_match_f32_and_are_bitwise_repeatable(dev, monkeypatch):
+    """mrmt3_tn_group_plan / _run: several weight gradients dW = dY^T X in one MFMA launch + one reduce.  Every shape of
+    the training step (ragged 384 / 768 / 1152 with their shifted last tiles, strided operand views, a token count that
+    is not a multiple of 128), mixed token counts in one group, accumulate on and off; against an f32 matmul of the same
+    bf16 operands, bit-identical when repeated (fixed summation order), and equal to the one-by-one kernels within f32
+    summation-order noise.  Reference op: autograd of nn.Linear(bias=False) wrt its weight (models/t5.py:51,72)."""
+    from mrmt3 import lib
+    torch.manual_seed(5)
+    shapes = [(65536, 512, 1024), (65536, 2048, 512), (65536, 512, 384), (65536, 384, 512), (16384, 768, 512),
+              (65536, 1152, 512), (16384 + 72, 512, 512), (4096, 1536, 512), (1024, 256, 256)]
+    for n_ctas in (None, "24"):           # the real chip, and a small grid (many rounds per workgroup)
+        if n_ctas:
+            monkeypatch.setenv("MRMT3_TN_GROUP_CTAS", n_ctas)
+            shapes = shapes[4:]
+        grp = lib.TnGroup()
+        sites = []
+        for i, (M, N1, N2) in enumerate(shapes):
+            wide = torch.randn(M, N1 + 128, device=dev).mul_(0.1).bfloat16()
+            a = wide[:, 64:64 + N1] if i % 2 else wide[:, :N1].contiguous()          # a strided view every other site
+            b = torch.randn(M, N2, device=dev).mul_(0.1).bfloat16()
+            acc = i % 3 == 0
+            out = torch.randn(N1, N2, device=dev) if acc else torch.full((N1, N2), float("nan"), device=dev)
+            init = out.clone()
+            assert lib.TnGroup.ok(a, b, out)
+            sites.append((a, b, out, acc, init))
+        for a, b, out, acc, _ in sites:
+            grp.add(a, b, out, accumulate=acc)
+        grp.flush()
+        info = grp.last_info
+        assert info.n_items >= info.n_ctas // 2 and info.rounds >= (1 if n_ctas is None else 4), (info.n_items, info.rounds)
+        firsts = []
+        for a, b, out, acc, init in sites:
+            ref = a.float().t() @ b.float()
+            if acc:
+                ref = ref + init
+            err = (out - ref).abs().max().item()
+            assert err < 3e-5 * ref.abs().max().item() + 1e-5, (a.shape, b.shape, err)
+            firsts.append(out.clone())
+            one = torch.zeros_like(out)
+            lib.gemm_tn(a, b, one)
+            if acc:
+                one += init
+            assert (out - one).abs().max().item() < 3e-5 * ref.abs().max().item() + 1e-5
+        for rep in range(3):               # same plan -> same bits
+            for a, b, out, acc, init in sites:
+                out.copy_(init)
+                grp.add(a, b, out, accumulate=acc)
+            grp.flush()
+            for (a, b, out, acc, init), f in zip(sites, firsts):
+                assert torch.equal(out, f)
+    assert not lib.TnGroup.ok(torch.zeros(512, 512, device=dev).bfloat16(), torch.zeros(512, 512, device=dev).bfloat16(),
+                              torch.zeros(512, 512, device=dev))         # too few rows: goes through mrmt3_gemm_tn
+    assert not lib.TnGroup.ok(torch.zeros(4096, 320, device=dev).bfloat16(), torch.zeros(4096, 512, device=dev).bfloat16(),
+                              torch.zeros(320, 512, device=dev))

@@ -129,7 +129,7 @@ def test_host_issue_time_of_a_replayed_step(dev):
         torch.cuda.synchronize()
     print("host issue per step: eager %.2f ms, graph %.2f ms" % (1e3 * times[False], 1e3 * times[True]))
     assert times[True] < 3e-3, times
-    assert times[True] < 0.4 * times[False], times
+    assert times[True] < 0.5 * times[False], times
 
 
 def test_a_failed_capture_falls_back_to_eager_steps(dev, monkeypatch):
