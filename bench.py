@@ -319,21 +319,13 @@ def main():
                                  "model_tflops": Bx * args.steps / dtx * FLOP_PER_SEG_FWD_BWD / 1e12}
     if not args.no_roofline:
         # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings.
-        # Pass 1 is the timed configuration: weight-gradient GEMMs run on a second stream, so a launch's
-        # event-to-event duration includes the time it shares the CUs with the kernel it overlaps.
-        # Pass 2 serialises everything on one stream: per-kernel durations in isolation.
+        # The replayed graph is ONE chain of kernels (the grouped weight-gradient launch included), so the eager repeat
+        # runs everything on one stream too and every launch is timed the way the graph executes it.
         n_rf = max(1, min(args.steps, 3))
         graph_was, trainer.use_graph = trainer.use_graph, False      # per-launch events need eager launches
         eng = trainer.engine
-        was = eng.overlap_wgrad
-        # Pass 1 = the timed configuration: the replayed graph is ONE chain of kernels (weight-gradient GEMMs included),
-        # so every launch is timed with everything serialised on one stream.
-        eng.overlap_wgrad = False
+        was, eng.overlap_wgrad = eng.overlap_wgrad, False
         fam = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), n_rf)
-        # Pass 2 = the eager fallback's configuration (MRMT3_TRAIN_GRAPH=0): weight-gradient GEMMs on a second stream,
-        # a launch's event-to-event duration then includes the time it shares the CUs with the kernel it overlaps.
-        eng.overlap_wgrad = True
-        fam_ovl = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), n_rf)
         eng.overlap_wgrad = was
         trainer.use_graph = graph_was
     if rank == 0 and not args.no_roofline:
@@ -342,7 +334,7 @@ def main():
         def rate(v):
             return v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "FLOP" else 1e9)
 
-        f, fo = fam[dom], fam_ovl[dom]
+        f = fam[dom]
         # HBM traffic of the dominant family: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction
         # of MI355X_MICROARCH.md) cannot run inside this process; the per-shape table they produced for this tree is
         # committed (profiles/r02_pmc_gemm_traffic.json, made by profiles/tools/pmc_traffic.sh) and folded in here
@@ -362,15 +354,11 @@ def main():
                            "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
                            "note": "HIP events around every launch of the family in an eager repeat of the timed steps, all "
                                    "kernels on one stream exactly as the replayed graph runs them (the timed steps "
-                                   "themselves are graph replays: events cannot be placed inside); "
-                                   "`eager_two_streams` = the same with the weight-gradient GEMMs overlapped on a "
-                                   "second stream (the MRMT3_TRAIN_GRAPH=0 fallback)",
+                                   "themselves are graph replays: events cannot be placed inside); the 16 wi projections "
+                                   "are timed with their gated-GELU epilogue; gemm_tn_bf16 = the grouped weight-gradient "
+                                   "launch + its reduce",
                            "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam.items()},
-                           "families_achieved": {k: rate(v) for k, v in fam.items()},
-                           "eager_two_streams": {"achieved": rate(fo), "frac": rate(fo) / PEAK_BF16_TFLOPS,
-                                                 "avg_launch_ms": fo["ms"] / fo["n"],
-                                                 "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam_ovl.items()},
-                                                 "families_achieved": {k: rate(v) for k, v in fam_ovl.items()}}}
+                           "families_achieved": {k: rate(v) for k, v in fam.items()}}
     sync()
     if rank == 0 and not args.no_inference:
         del trainer, model

@@ -122,7 +122,7 @@ typedef struct {
 } mrmt3_tn_gsite;
 typedef struct {
   int32_t n_ctas, n_items, n_rtiles, rounds;
-  uint64_t rtile_offset, table_bytes, slab_bytes;
+  uint64_t rtile_offset, list_offset, sync_offset, table_bytes, slab_bytes;
 } mrmt3_tn_group_info;
 int mrmt3_tn_group_ok(int M, int N1, int N2, int lda, int ldb, int ldc);
 int mrmt3_tn_group_plan(const mrmt3_tn_gsite* sites, int n_sites, void* slab_dev, void* table_host, size_t table_cap,

@@ -18,6 +18,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -45,7 +49,7 @@ struct T8Item {
   int a0, b0;          // tile origin (a shifted last tile starts at N - 256) ...
   int rmin, cmin;      // ... and the first n1 / n2 it owns
   int row0, nk;        // token range: rows row0 .. row0 + 64 nk (nk even)
-  int pad;
+  int sync_idx, sync_n; // grouped launch: the sync_n items of a shelf wait for each other before they start (0: no wait)
 };
 static_assert(sizeof(T8Item) == 80, "item layout (the planner writes these records on the host)");
 // One gradient tile of a grouped launch: C[owned part of the tile] (+)= sum of its n_part partial tiles, in order.
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(T8Params P) {
   I.a0 = min(t1 * 256, P.N1 - 256); I.b0 = min(t2 * 256, P.N2 - 256);
   I.rmin = t1 * 256; I.cmin = t2 * 256;
   I.row0 = split * P.rows_per_split; I.nk = P.rows_per_split >> 6;     // (rows_per_split is a multiple of 128)
-  I.pad = 0;
+  I.sync_idx = 0; I.sync_n = 0;
   t8_run_item(I, lds);
 }
 
@@ -262,13 +266,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(T8Params P) {
 // of a whole gradient bucket alive instead (memory is not the constraint on this part) and launches its gradients
 // together: items (gradient, token range, tile) of nearly equal length, planned on the host (mrmt3_tn_group_plan) so that
 // the item count is a whole number of rounds over the CUs — 2-8 partial tiles per gradient tile, 100-400 K steps per item.
-// Workgroup l (logical index: XCD-major, so that the tiles of one token range share an L2) runs items l, l + G, ...
-__global__ __launch_bounds__(512, 2) void gemm_tn8_group_kernel(const T8Item* __restrict__ items, int n_items) {
+// Workgroup l (logical index: XCD-major, so that the tiles of one token range share an L2) runs its own list of items
+// (longest first; the planner deals the items, longest first, to the least loaded workgroup).
+__global__ __launch_bounds__(512, 2) void gemm_tn8_group_kernel(const T8Item* __restrict__ items,
+                                                                  const int* __restrict__ cta_start,
+                                                                  const int* __restrict__ cta_items, int* sync) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * T8_BUF];
   const int n = (int)gridDim.x, per = n >> 3;
   const int l = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  for (int j = l; j < n_items; j += n) {
-    const T8Item I = items[j];
+  const int q1 = cta_start[l + 1];
+  for (int q = cta_start[l]; q < q1; ++q) {
+    const T8Item I = items[cta_items[q]];
+    if (I.sync_n > 1) {
+      // The items of a shelf share their operand rows through the XCD's L2 only while they walk the rows together:
+      // wait (bounded: this is a performance hint, never a correctness condition — a workgroup that is not resident
+      // yet must not hang the others) until the shelf's other items have arrived.  Once in step they stay in step:
+      // whoever runs ahead takes the L2 misses.
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(sync + I.sync_idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(sync + I.sync_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < I.sync_n &&
+               __builtin_amdgcn_s_memrealtime() - t0 < 3000ull)        // 30 us at 100 MHz
+          __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();
+    }
     t8_run_item(I, lds);
   }
 }
@@ -374,34 +396,137 @@ extern "C" int mrmt3_tn_group_plan(const mrmt3_tn_gsite* sites, int n_sites, voi
     W += (double)sp[s].T * sp[s].U;
   }
   const double OVH = 2.0, US_PER_UNIT = 2.9, US_PER_ITEM = 0.12;
-  double best = 1e30;
-  std::vector<int> bestR(n_sites, 1), load(G);
-  for (int k = 1; k <= 8; ++k)
-    for (int fi = 0; fi <= 12; ++fi) {
-      const double Lt = W / ((double)k * G) * (0.76 + 0.045 * fi);
-      if (Lt < 8.0 && !(k == 1 && fi == 12)) continue;       // at least 1024 rows behind a 256 KiB partial tile
-      std::vector<int> R(n_sites), len(n_sites), order(n_sites);
-      for (int s = 0; s < n_sites; ++s) {
-        int r = (int)((double)sp[s].U / (Lt < 8.0 ? 8.0 : Lt) + 0.5);
-        const int rmax = sp[s].U / 8 > 0 ? sp[s].U / 8 : 1;
-        r = r < 1 ? 1 : (r > rmax ? rmax : r);
-        len[s] = ceil_div(sp[s].U, r);
-        R[s] = ceil_div(sp[s].U, len[s]);
-        order[s] = s;
+  std::vector<int> bestR(n_sites, 1);
+  // Cost of cutting gradient s into R[s] token ranges.  The tiles of one (gradient, token range) — a GROUP — read the
+  // same rows of dY and X, and a 256 x 256 tile needs 128 flop per operand byte: 11 TB/s at full MFMA rate unless the
+  // tiles of a group run on one XCD AT THE SAME TIME and share the rows through its L2 (measured with the groups dealt to
+  // workgroups one by one, longest first: 17.7 GB fetched against 11 GB of operands; 13.3 GB with the groups kept
+  // together).  So the unit of scheduling is the group and the machine is 8 XCDs x (G/8) lanes: a group, longest first,
+  // goes to the XCD where as many lanes as it has tiles are free the earliest, and its items start together.
+  const int LANES = G / 8;
+  struct Grp { int s, r, t0, T, len, xcd; std::vector<int> lanes; };
+  std::vector<Grp> groups;
+  std::vector<int> placed_order;
+  auto pack = [&](const std::vector<int>& R) -> double {
+    groups.clear();
+    long n_it = 0;
+    for (int s = 0; s < n_sites; ++s) {
+      const int len = ceil_div(sp[s].U, R[s]), R_s = ceil_div(sp[s].U, len);
+      for (int r = 0; r < R_s; ++r)
+        for (int t0 = 0; t0 < sp[s].T; t0 += LANES)           // (a gradient of more than G/8 tiles: several groups)
+          groups.push_back({s, r, t0, std::min(LANES, sp[s].T - t0), std::min(len, sp[s].U - r * len), 0, {}});
+      n_it += (long)R_s * sp[s].T;
+    }
+    placed_order.resize(groups.size());
+    for (size_t i = 0; i < groups.size(); ++i) placed_order[i] = (int)i;
+    std::stable_sort(placed_order.begin(), placed_order.end(), [&](int a, int b) {
+      return groups[a].len != groups[b].len ? groups[a].len > groups[b].len : groups[a].T > groups[b].T;
+    });
+    // list scheduling of rigid jobs: a group takes T lanes of ONE XCD from the moment T of its lanes are free
+    std::vector<long> free_at((size_t)8 * LANES, 0);
+    std::vector<std::pair<long, int>> lf(LANES);
+    long mk = 0;
+    for (int gi : placed_order) {
+      Grp& g2 = groups[gi];
+      int bx = 0;
+      long bstart = -1, bwaste = 0;
+      for (int x = 0; x < 8; ++x) {
+        for (int l2 = 0; l2 < LANES; ++l2) lf[l2] = {free_at[(size_t)x * LANES + l2], l2};
+        std::partial_sort(lf.begin(), lf.begin() + g2.T, lf.end());
+        const long start = lf[g2.T - 1].first;
+        long waste = 0;
+        for (int l2 = 0; l2 < g2.T; ++l2) waste += start - lf[l2].first;
+        if (bstart < 0 || start < bstart || (start == bstart && waste < bwaste)) { bstart = start; bwaste = waste; bx = x; }
       }
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
-      std::fill(load.begin(), load.end(), 0);
-      long j = 0;
-      for (int oi = 0; oi < n_sites; ++oi) {
-        const int s = order[oi];
-        for (int r = 0; r < R[s]; ++r) {
-          const int bl = std::min(len[s], sp[s].U - r * len[s]);
-          for (int t = 0; t < sp[s].T; ++t, ++j) load[j % G] += bl + (int)OVH;
+      for (int l2 = 0; l2 < LANES; ++l2) lf[l2] = {free_at[(size_t)bx * LANES + l2], l2};
+      std::partial_sort(lf.begin(), lf.begin() + g2.T, lf.end());
+      g2.xcd = bx;
+      g2.lanes.resize(g2.T);
+      for (int l2 = 0; l2 < g2.T; ++l2) {
+        g2.lanes[l2] = lf[l2].second;
+        free_at[(size_t)bx * LANES + lf[l2].second] = bstart + g2.len + (long)OVH;
+      }
+      mk = std::max(mk, bstart + g2.len + (long)OVH);
+    }
+    return (double)mk * US_PER_UNIT + (double)n_it * US_PER_ITEM;
+  };
+  auto evaluate = [&](const std::vector<int>& R) -> double { return pack(R); };
+  // the search depends on the shapes only: remembered per (shapes, G) so that a re-plan for new addresses is cheap
+  static std::mutex memo_mu;
+  static std::map<std::vector<int>, std::vector<int>> memo;
+  std::vector<int> memo_key;
+  memo_key.push_back(G);
+  for (int s = 0; s < n_sites; ++s) { memo_key.push_back(sites[s].M); memo_key.push_back(sites[s].N1); memo_key.push_back(sites[s].N2); }
+  bool have = false;
+  {
+    std::lock_guard<std::mutex> lk(memo_mu);
+    auto it = memo.find(memo_key);
+    if (it != memo.end()) { bestR = it->second; have = true; }
+  }
+  if (!have) {
+    double best = 1e30;
+    auto clampR = [&](int s, int r) { const int rmax = sp[s].U / 8 > 0 ? sp[s].U / 8 : 1; return r < 1 ? 1 : (r > rmax ? rmax : r); };
+    // (1) one target item length for every gradient ...
+    for (int k = 1; k <= 12; ++k)
+      for (int fi = 0; fi <= 40; ++fi) {
+        const double Lt = W / ((double)k * G) * (0.70 + 0.015 * fi);
+        if (Lt < 8.0 && !(k == 1 && fi == 40)) continue;     // at least 1024 rows behind a 256 KiB partial tile
+        std::vector<int> R(n_sites);
+        for (int s = 0; s < n_sites; ++s) {
+          const int r = clampR(s, (int)((double)sp[s].U / (Lt < 8.0 ? 8.0 : Lt) + 0.5));
+          R[s] = ceil_div(sp[s].U, ceil_div(sp[s].U, r));
+        }
+        const double cost = evaluate(R);
+        if (cost < best) { best = cost; bestR = R; }
+      }
+    // (1b) ... or one number of ranges per token count (a step has two or three: decoder rows, encoder rows, memory rows):
+    // every combination — this is what finds "decoder gradients in 4 ranges, encoder gradients whole" when that makes
+    // all items the same length and the shelves come out even
+    {
+      std::vector<int> classes;
+      for (int s = 0; s < n_sites; ++s)
+        if (std::find(classes.begin(), classes.end(), sp[s].U) == classes.end()) classes.push_back(sp[s].U);
+      if (classes.size() <= 3) {
+        std::vector<int> rc(classes.size(), 1), R(n_sites);
+        for (;;) {
+          for (int s = 0; s < n_sites; ++s) {
+            const int c = (int)(std::find(classes.begin(), classes.end(), sp[s].U) - classes.begin());
+            const int r = clampR(s, rc[c]);
+            R[s] = ceil_div(sp[s].U, ceil_div(sp[s].U, r));
+          }
+          const double cost = evaluate(R);
+          if (cost < best) { best = cost; bestR = R; }
+          size_t c = 0;
+          for (; c < classes.size(); ++c) {
+            if (++rc[c] <= std::min(16, std::max(1, classes[c] / 8))) break;
+            rc[c] = 1;
+          }
+          if (c == classes.size()) break;
         }
       }
-      const double cost = *std::max_element(load.begin(), load.end()) * US_PER_UNIT + (double)j * US_PER_ITEM;
-      if (cost < best) { best = cost; bestR = R; }
     }
+    // (2) ... then single gradients take one range more or fewer while that shortens the busiest workgroup
+    for (int pass = 0; pass < 40; ++pass) {
+      int bs = -1, br = 0;
+      double bc = best - 1e-9;
+      for (int s = 0; s < n_sites; ++s)
+        for (int d = -1; d <= 1; d += 2) {
+          const int r = clampR(s, bestR[s] + d);
+          if (r == bestR[s] || ceil_div(sp[s].U, ceil_div(sp[s].U, r)) != r) continue;
+          const int keep = bestR[s];
+          bestR[s] = r;
+          const double c = evaluate(bestR);
+          bestR[s] = keep;
+          if (c < bc) { bc = c; bs = s; br = r; }
+        }
+      if (bs < 0) break;
+      bestR[bs] = br;
+      best = bc;
+    }
+    std::lock_guard<std::mutex> lk(memo_mu);
+    if (memo.size() > 64) memo.clear();
+    memo[memo_key] = bestR;
+  }
   // ---- emit
   std::vector<int> order(n_sites), len(n_sites);
   long n_items = 0, n_rt = 0;
@@ -414,12 +539,17 @@ extern "C" int mrmt3_tn_group_plan(const mrmt3_tn_gsite* sites, int n_sites, voi
   }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
   const size_t items_bytes = ((size_t)n_items * sizeof(T8Item) + 63) & ~(size_t)63;
+  const size_t rt_bytes = ((size_t)n_rt * sizeof(T8RTile) + 63) & ~(size_t)63;
   info->n_ctas = G;
   info->n_items = (int)n_items;
   info->n_rtiles = (int)n_rt;
   info->rounds = (int)((n_items + G - 1) / G);
   info->rtile_offset = (uint64_t)items_bytes;
-  info->table_bytes = (uint64_t)(items_bytes + (size_t)n_rt * sizeof(T8RTile));
+  info->list_offset = (uint64_t)(items_bytes + rt_bytes);            // int cta_start[G + 1], int cta_items[n_items]
+  pack(bestR);                                               // the schedule of the chosen plan
+  const size_t list_bytes = ((((size_t)(G + 1) + (size_t)n_items) * sizeof(int)) + 63) & ~(size_t)63;
+  info->sync_offset = (uint64_t)(items_bytes + rt_bytes + list_bytes);   // int arrived[n_groups], zero in the host table
+  info->table_bytes = (uint64_t)(items_bytes + rt_bytes + list_bytes + groups.size() * sizeof(int));
   info->slab_bytes = (uint64_t)n_items * 65536ull * sizeof(float);
   if (!table_host) return MRMT3_OK;                          // sizing pass
   MR_CHECK_ARG(slab_dev && table_cap >= info->table_bytes, "tn_group_plan: table buffer too small or no slab buffer");
@@ -427,12 +557,17 @@ extern "C" int mrmt3_tn_group_plan(const mrmt3_tn_gsite* sites, int n_sites, voi
   T8RTile* rts = (T8RTile*)((char*)table_host + items_bytes);
   memset(table_host, 0, (size_t)info->table_bytes);
   float* slab = (float*)slab_dev;
+  int* cta_start = (int*)((char*)table_host + info->list_offset);
+  int* cta_items = cta_start + G + 1;
+  std::vector<std::vector<int>> lists(G);
+  std::vector<long> item0(n_sites);                          // item (s, r, t) = item0[s] + r * T + t
   long j = 0, slab_idx = 0, rt = 0;
   for (int oi = 0; oi < n_sites; ++oi) {
     const int s = order[oi];
     const mrmt3_tn_gsite& S = sites[s];
     const SP& p = sp[s];
     const long base = slab_idx;                              // partial tile (t, r) of this gradient: base + t * R + r
+    item0[s] = j;
     for (int r = 0; r < p.R; ++r) {
       const int bl = std::min(p.len, p.U - r * p.len);
       for (int t = 0; t < p.T; ++t, ++j) {
@@ -457,6 +592,23 @@ extern "C" int mrmt3_tn_group_plan(const mrmt3_tn_gsite* sites, int n_sites, voi
     }
     slab_idx += (long)p.T * p.R;
   }
+  for (int gi : placed_order) {                              // schedule -> per-workgroup item lists, in start order
+    const Grp& g2 = groups[gi];
+    for (int t = 0; t < g2.T; ++t) {
+      const long it = item0[g2.s] + (long)g2.r * sp[g2.s].T + g2.t0 + t;
+      lists[g2.xcd * LANES + g2.lanes[t]].push_back((int)it);
+      items[it].sync_idx = gi;
+      items[it].sync_n = g2.T;
+    }
+  }
+  int q = 0, rounds = 0;
+  for (int c = 0; c < G; ++c) {
+    cta_start[c] = q;
+    for (int it : lists[c]) cta_items[q++] = it;
+    rounds = std::max(rounds, (int)lists[c].size());
+  }
+  cta_start[G] = q;
+  info->rounds = rounds;
   return MRMT3_OK;
 }
 
@@ -470,8 +622,9 @@ extern "C" int mrmt3_tn_group_run(void* table_dev, const void* table_host, const
       return MRMT3_ERR_HIP;
     }
   }
+  const int* cta_start = (const int*)((const char*)table_dev + info->list_offset);
   hipLaunchKernelGGL(gemm_tn8_group_kernel, dim3((unsigned)info->n_ctas), dim3(512), 0, s, (const T8Item*)table_dev,
-                     info->n_items);
+                     cta_start, cta_start + info->n_ctas + 1, (int*)((char*)table_dev + info->sync_offset));
   MR_CHECK_LAUNCH("tn_group_run");
   hipLaunchKernelGGL(tn8_group_reduce_kernel, dim3((unsigned)info->n_rtiles * 64u), dim3(256), 0, s,
                      (const T8RTile*)((const char*)table_dev + info->rtile_offset));

@@ -280,7 +280,7 @@ class _TnGSite(C.Structure):          # = mrmt3_tn_gsite
 
 class _TnGInfo(C.Structure):          # = mrmt3_tn_group_info
     _fields_ = [(n, C.c_int32) for n in ("n_ctas", "n_items", "n_rtiles", "rounds")] + \
-               [(n, C.c_uint64) for n in ("rtile_offset", "table_bytes", "slab_bytes")]
+               [(n, C.c_uint64) for n in ("rtile_offset", "list_offset", "sync_offset", "table_bytes", "slab_bytes")]
 
 
 class _PinnedTable:
@@ -537,8 +537,9 @@ def gemm_nt_geglu(x, wi, p=0.0, seed=0, stream_id=0, step=None):
     two = wi.shape[0]
     h = torch.empty(rows, two, device=x.device, dtype=torch.bfloat16)
     g = torch.empty(rows, two // 2, device=x.device, dtype=torch.bfloat16)
-    _check(load().mrmt3_gemm_nt_geglu(_p(x), x.stride(0), _p(wi), wi.stride(0), _p(h), two, _p(g), two // 2, rows,
-                                      two // 2, K, p, seed, _p(step), stream_id, _stream()), "gemm_nt_geglu")
+    with _Timed("gemm_nt_bf16", 2.0 * rows * two * K, "FLOP"):      # (the launch includes the gated-GELU epilogue)
+        _check(load().mrmt3_gemm_nt_geglu(_p(x), x.stride(0), _p(wi), wi.stride(0), _p(h), two, _p(g), two // 2, rows,
+                                          two // 2, K, p, seed, _p(step), stream_id, _stream()), "gemm_nt_geglu")
     return h, g
 
 

@@ -145,7 +145,7 @@ def test_grouped_weight_gradient_plan_covers_every_tile_once():
     assert lib.mrmt3_tn_group_plan(arr, len(shapes), C.c_void_p(slab0), C.c_void_p(host.ctypes.data), host.size, C.byref(info)) == 0
     item_t = np.dtype([("A", "<u8"), ("B", "<u8"), ("out", "<u8"), ("lda", "<i4"), ("ldb", "<i4"), ("ldo", "<i4"),
                        ("M", "<i4"), ("N1", "<i4"), ("N2", "<i4"), ("a0", "<i4"), ("b0", "<i4"), ("rmin", "<i4"),
-                       ("cmin", "<i4"), ("row0", "<i4"), ("nk", "<i4"), ("pad", "<i4"), ("pad2", "<i4")])
+                       ("cmin", "<i4"), ("row0", "<i4"), ("nk", "<i4"), ("sync_idx", "<i4"), ("sync_n", "<i4")])
     rt_t = np.dtype([("slab", "<u8"), ("C", "<u8"), ("ldc", "<i4"), ("a0", "<i4"), ("b0", "<i4"), ("rmin", "<i4"),
                      ("cmin", "<i4"), ("n_part", "<i4"), ("acc", "<i4"), ("pad", "<i4")])
     assert item_t.itemsize == 80 and rt_t.itemsize == 48
@@ -176,7 +176,20 @@ def test_grouped_weight_gradient_plan_covers_every_tile_once():
         for p in range(int(rt["n_part"])):
             listed.add(int(rt["slab"]) + p * 256 * 1024)
     assert listed == slabs
-    load = np.zeros(info.n_ctas)
-    for j, it in enumerate(items):
-        load[j % info.n_ctas] += it["nk"]
-    assert load.max() <= 1.15 * load.mean(), (load.max(), load.mean())
+    # per-workgroup lists: every item exactly once; the items of a shelf sit on one XCD's lanes and agree on its size
+    lst = np.frombuffer(host[info.list_offset:info.list_offset + 4 * (info.n_ctas + 1 + info.n_items)].tobytes(), dtype="<i4")
+    start, ids = lst[:info.n_ctas + 1], lst[info.n_ctas + 1:]
+    assert start[0] == 0 and start[-1] == info.n_items and sorted(ids.tolist()) == list(range(info.n_items))
+    load = np.array([sum(int(items["nk"][i]) for i in ids[start[c]:start[c + 1]]) for c in range(info.n_ctas)])
+    assert load.max() <= 1.25 * load.mean(), (load.max(), load.mean())
+    lanes = info.n_ctas // 8
+    shelf_xcd, shelf_cnt = {}, {}
+    for c in range(info.n_ctas):
+        for i in ids[start[c]:start[c + 1]]:
+            sh = int(items["sync_idx"][i])
+            assert shelf_xcd.setdefault(sh, c // lanes) == c // lanes
+            shelf_cnt[sh] = shelf_cnt.get(sh, 0) + 1
+            assert 1 <= items["sync_n"][i] <= lanes
+    for i in range(info.n_items):
+        assert shelf_cnt[int(items["sync_idx"][i])] == items["sync_n"][i]
+    assert not host[info.sync_offset:info.sync_offset + 4 * len(shelf_cnt)].any()          # the arrival counters start at zero
