@@ -355,8 +355,8 @@ def main():
                            "note": "HIP events around every launch of the family in an eager repeat of the timed steps, all "
                                    "kernels on one stream exactly as the replayed graph runs them (the timed steps "
                                    "themselves are graph replays: events cannot be placed inside); the 16 wi projections "
-                                   "are timed with their gated-GELU epilogue; gemm_tn_bf16 = the grouped weight-gradient "
-                                   "launch + its reduce",
+                                   "(GEMM + gated-GELU epilogue in one launch) are their own family gemm_nt_geglu_bf16, "
+                                   "priced at the GEMM's FLOPs; gemm_tn_bf16 = the grouped weight-gradient launch + its reduce",
                            "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam.items()},
                            "families_achieved": {k: rate(v) for k, v in fam.items()}}
     sync()

@@ -27,7 +27,9 @@ def layer_ranges(flat) -> "List[Tuple[str, int, int]]":
         for s in flat.shapes[key]:
             n *= s
         parts = key.split(".")
-        if parts[0] in ("encoder", "decoder", "segmem_encoder") and parts[1] == "block":
+        if parts[0] == "decoder" and parts[1] == "block" and parts[5] == "EncDecAttention" and parts[6] in ("k", "v"):
+            tag = "decoder.ckv"          # the cross k|v projections of all layers sit together (params.py)
+        elif parts[0] in ("encoder", "decoder", "segmem_encoder") and parts[1] == "block":
             tag = f"{parts[0]}.{parts[2]}"
         elif parts[0] in ("encoder", "decoder", "segmem_encoder"):
             tag = f"{parts[0]}.final"
@@ -81,6 +83,8 @@ class GradBuckets:
             tags = [f"decoder.{i}" for i in range(lo, hi + 1)]
             if hi == n_layers_dec - 1:
                 tags += ["decoder.final", "lm_head"]
+            if lo == 0 and "decoder.ckv" in rng:
+                tags = ["decoder.ckv"] + tags          # complete when the last (lowest) decoder layer is done
             add(tags, ("decoder", lo))
         for hi in range(n_layers_enc - 1, -1, -layers_per_bucket):
             lo = max(hi - layers_per_bucket + 1, 0)

@@ -159,6 +159,8 @@ class Engine:
         keep = tape is not None
         y = None
         sy = 0
+        # cross-attention K | V of every layer in one projection of the encoder output: [B*Le, n_layers * 768]
+        kv_all = lib.gemm_nt(enc, self.W(f"{prefix}.ckv_all")) if is_decoder and n_layers > 0 else None
         for i in range(n_layers):
             b = f"{prefix}.block.{i}.layer"
             # -- self attention
@@ -181,7 +183,7 @@ class Engine:
                 x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.1.layer_norm.weight"), eps, dt,
                                                   p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
                 q = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.cq"))
-                kv = lib.gemm_nt(enc, self.W(f"{prefix}.{i}.ckv"))
+                kv = kv_all[:, i * 2 * inner:(i + 1) * 2 * inner]        # this layer's K | V columns (row stride n_layers * 768)
                 s_att = self._sid()
                 o, lse, o_lo = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, L, Le, False, p=p, seed=self.seed,
                                             step=self.step_dev, stream_id=s_att, want_lse=keep, want_lo=keep)
@@ -229,6 +231,10 @@ class Engine:
         dx, dy = self._norm_bwd(d_out, None, fin["x1"], fin["rstd"], self.ln(f"{prefix}.final_layer_norm.weight"),
                                      f.grad(f"{prefix}.final_layer_norm.weight"), want_dy=has_y, p=p, seed=seed, step=self.step_dev,
                                      stream_y=fin["s_in"], stream_out=fin["s_out"], out_drop=True, dx1_dtype=rg)
+        # gradient of the cross-attention K | V of every layer, side by side like the forward's kv_all: the gradient of
+        # the encoder output is then ONE product with K = n_layers * 768 after the loop instead of n_layers f32 accumulations
+        dkv_all = (torch.empty(B * Le, n_layers * 2 * inner, device=d_out.device, dtype=self.dt)
+                   if is_dec and n_layers > 0 else None)
         for i in reversed(range(n_layers)):
             b = f"{prefix}.block.{i}.layer"
             t = tape.pop()
@@ -248,14 +254,13 @@ class Engine:
                 self.wgrad(dy, t["o"], f.GW(f"{prefix}.{i}.co"))
                 do = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.co"))
                 dq = torch.empty_like(t["q"])
-                dkv = torch.empty_like(t["kv"])
+                dkv = dkv_all[:, i * 2 * inner:(i + 1) * 2 * inner]
                 kv = t["kv"]
                 lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
                              dkv[:, inner:], B, H, L, Le, False, p=p, seed=seed, step=self.step_dev,
                              stream_id=t["s_att"], o_lo=t["o_lo"])
                 self.wgrad(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"))
                 self.wgrad(dkv, enc, f.GW(f"{prefix}.{i}.ckv"))
-                lib.gemm_nt(dkv, f.WT(f"{prefix}.{i}.ckv"), out=d_enc, accumulate=True)
                 dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
                 dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
                                              f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
@@ -277,6 +282,8 @@ class Engine:
                                          stream_y=t["s_in"], dx1=None if (last and dx.dtype != torch.float32) else dx)
             if on_layer_done is not None:
                 on_layer_done(prefix, i)
+        if dkv_all is not None:
+            lib.gemm_nt(dkv_all, f.WT(f"{prefix}.ckv_all"), out=d_enc)          # d_enc is written here and nowhere else
         return dx
 
     # ---- model pieces ------------------------------------------------------------------------------------
@@ -505,7 +512,7 @@ class Engine:
             full = torch.zeros(B, Lx, d, device=d_dec.device, dtype=torch.float32)
             full[:, Ls:] = d_dec.view(B, Ld, d)
             d_dec = full.view(B * Lx, d)
-        d_enc_cat = torch.zeros(B * Lc, d, device=d_dec.device, dtype=torch.float32)
+        d_enc_cat = torch.empty(B * Lc, d, device=d_dec.device, dtype=torch.float32)      # written by stack_bwd's one d_enc product
         dx = self.stack_bwd(tape, d_dec, d_enc=d_enc_cat, on_layer_done=on_layer_done)
         t = tape.pop()
         assert t["kind"] == "dec_in"

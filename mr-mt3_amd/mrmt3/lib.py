@@ -371,8 +371,11 @@ class TnGroup:
             table = torch.empty(int(info.table_bytes), device=dev, dtype=torch.uint8)
             ent = dict(host=host, table=table, info=info, flops=flops, slab=self._slab, captured=capturing)
             if not capturing:
-                if not any(h.nbytes >= host.nbytes for h in self._spare):
-                    self._spare.append(_PinnedTable(host.nbytes))
+                # one spare per eager plan: a step with several joins (one per gradient bucket) needs as many tables
+                # when it is captured
+                self._spare.append(_PinnedTable(host.nbytes))
+                if len(self._spare) > 64:
+                    self._spare.pop(0)
                 eager = [k for k, e in self._plans.items() if not e["captured"]]
                 if len(eager) >= 128:                          # eager address churn (steady state reuses addresses)
                     torch.cuda.current_stream().synchronize()  # their table copies have been consumed
@@ -537,7 +540,7 @@ def gemm_nt_geglu(x, wi, p=0.0, seed=0, stream_id=0, step=None):
     two = wi.shape[0]
     h = torch.empty(rows, two, device=x.device, dtype=torch.bfloat16)
     g = torch.empty(rows, two // 2, device=x.device, dtype=torch.bfloat16)
-    with _Timed("gemm_nt_bf16", 2.0 * rows * two * K, "FLOP"):      # (the launch includes the gated-GELU epilogue)
+    with _Timed("gemm_nt_geglu_bf16", 2.0 * rows * two * K, "FLOP"):      # (its own family: GEMM + gated-GELU epilogue)
         _check(load().mrmt3_gemm_nt_geglu(_p(x), x.stride(0), _p(wi), wi.stride(0), _p(h), two, _p(g), two // 2, rows,
                                           two // 2, K, p, seed, _p(step), stream_id, _stream()), "gemm_nt_geglu")
     return h, g

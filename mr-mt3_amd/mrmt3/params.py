@@ -26,10 +26,25 @@ class FlatParams:
         self.shapes = state_dict_shapes(cfg, segmem_num_layers)
         self.offsets: "OrderedDict[str, int]" = OrderedDict()
         off = 0
-        for k, shp in self.shapes.items():
+        # Flat order = state-dict order, except that the cross-attention k|v projections of ALL decoder layers sit
+        # together in front of decoder block 0: they all multiply the same encoder output, so the forward projects it for
+        # every layer in one [n_layers * 768, 512] GEMM and the backward returns its gradient in one GEMM with
+        # K = n_layers * 768 ("decoder.ckv_all"); the per-layer [768, 512] views stay valid.
+        n_dec = cfg["num_decoder_layers"]
+        ckv = [f"decoder.block.{i}.layer.1.EncDecAttention.{n}.weight" for i in range(n_dec) for n in ("k", "v")]
+        ckv_set = set(ckv)
+        order = []
+        for k in self.shapes:
+            if k in ckv_set:
+                continue
+            if k == "decoder.block.0.layer.0.SelfAttention.q.weight":
+                order.extend(ckv)
+            order.append(k)
+        assert len(order) == len(self.shapes)
+        for k in order:
             self.offsets[k] = off
             n = 1
-            for s in shp:
+            for s in self.shapes[k]:
                 n *= s
             off += n
         self.numel = off
@@ -73,14 +88,20 @@ class FlatParams:
         add("proj", "proj.weight", d, d)
         stack("encoder", cfg["num_layers"], False)
         stack("decoder", cfg["num_decoder_layers"], True)
+        if cfg["num_decoder_layers"] > 0:
+            add("decoder.ckv_all", "decoder.block.0.layer.1.EncDecAttention.k.weight", cfg["num_decoder_layers"] * 2 * inner, d)
         add("lm_head", "lm_head.weight", cfg["vocab_size"], d)
         if segmem_num_layers:
             add("segmem_proj", "segmem_proj.weight", d, d)
             stack("segmem_encoder", segmem_num_layers, False)
         self.groups = g
+        # pre-transposed (dgrad) copies: every group but proj (the mel input needs no gradient) and the per-layer
+        # cross k|v views (their dgrad is the one K = n_layers * 768 product against "decoder.ckv_all")
         self.t_offsets = OrderedDict()
         off = 0
         for name, (_, r, c) in g.items():
+            if name == "proj" or (name.startswith("decoder.") and name.endswith(".ckv")):
+                continue
             self.t_offsets[name] = off
             off += r * c
         self.t_numel = off
@@ -171,8 +192,8 @@ class FlatParams:
         if getattr(self, "_tr_tab", None) is None:
             rec, starts, tot = [], [], 0
             for name, (o, r, c) in self.groups.items():
-                if name == "proj":
-                    continue  # the mel input needs no gradient
+                if name not in self.t_offsets:
+                    continue
                 rec.append((o, self.t_offsets[name], r, c))
                 starts.append(tot)
                 tot += ((r + 63) // 64) * ((c + 63) // 64)       # 64x64 tiles (csrc/rowops.hip TRB)

