@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   //     row tiles of r1 (final after ph4)                         -> ph1, ph2 of the NEXT tile (overwritten in its ph3)
   // Stores share the in-order vmcnt queue with the loads: the counted waits of these K steps allow for the batches
   // that are younger than the load they wait for.
-  auto store_rows = [&](int i0, int m0, int n0, int cmin, bool count) {
+  auto store_rows = [&](int i0, int m0, int n0, int cmin, bool count) __attribute__((always_inline)) {
     if (P.dbg & 1) return;
     if constexpr (EPI == 1) {
       // gated GELU: three 16-byte stores per row tile (h0, h1, g), rows on fr, 8 features per lane
