@@ -333,13 +333,13 @@ class TnGroup:
         return len(self._sites)
 
     def _host_table(self, nbytes, capturing):
+        if not capturing:
+            return _PinnedTable(nbytes)         # (the spares are for captures only: an eager plan must not use one up)
         fit = [i for i, h in enumerate(self._spare) if h.nbytes >= nbytes]
-        if fit:
-            return self._spare.pop(min(fit, key=lambda i: self._spare[i].nbytes))
-        if capturing:
+        if not fit:
             raise RuntimeError("TnGroup: no page-locked table of %d bytes was prepared before the capture "
                                "(run the step eagerly once with the same shapes first)" % nbytes)
-        return _PinnedTable(nbytes)
+        return self._spare.pop(min(fit, key=lambda i: self._spare[i].nbytes))
 
     def flush(self):
         if not self._sites:
@@ -365,6 +365,9 @@ class TnGroup:
             if self._slab is None or self._slab.numel() < info.slab_bytes:
                 self._slab = None
                 self._slab = torch.empty(int(info.slab_bytes), device=dev, dtype=torch.uint8)
+            if os.environ.get("MRMT3_TN_GROUP_DEBUG"):
+                print("TnGroup plan: sites", n, "table", int(info.table_bytes), "capturing", capturing, "spares",
+                      [h.nbytes for h in self._spare], "plans", len(self._plans), flush=True)
             host = self._host_table(int(info.table_bytes), capturing)
             _check(L.mrmt3_tn_group_plan(arr, n, _p(self._slab), C.c_void_p(host.ptr), host.nbytes, C.byref(info)),
                    "tn_group_plan")
@@ -373,7 +376,7 @@ class TnGroup:
             if not capturing:
                 # one spare per eager plan: a step with several joins (one per gradient bucket) needs as many tables
                 # when it is captured
-                self._spare.append(_PinnedTable(host.nbytes))
+                self._spare.append(_PinnedTable(int(info.table_bytes)))
                 if len(self._spare) > 64:
                     self._spare.pop(0)
                 eager = [k for k, e in self._plans.items() if not e["captured"]]
