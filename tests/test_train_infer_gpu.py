@@ -438,3 +438,35 @@ def test_bf16_training_trajectory_tracks_the_fp32_oracle(dev, variant):
         worst = max(worst, 1.0 - cos)
         assert cos > 0.99, (k, cos)                                  # measured worst 0.9976
     print(variant, "worst 1 - cos(update):", worst)
+
+
+def test_step_gradients_do_not_depend_on_the_launch_structure(dev, monkeypatch):
+    """One backward, three ways of launching it: (a) the default (weight gradients grouped into one launch, wi projection
+    fused with the gated GELU, cross k|v of all layers from one projection), (b) the wi projection and the GELU as two
+    kernels — bit-identical by construction, so the whole gradient must be — and (c) one launch per weight gradient —
+    a different f32 summation order over the token rows, so equal to rounding noise only."""
+    from mrmt3.synthetic import synth_mel, synth_labels
+    from mrmt3.trainer import Trainer
+    mel = torch.from_numpy(synth_mel(8)).to(dev)
+    lab = torch.from_numpy(synth_labels(8, 1024, full=True, seed=3)).to(dev)
+
+    def grads(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = _model("t5", dev, dropout_rate=0.1)
+        tr = Trainer(m, lr=0.0, graph=False)
+        loss = tr.train_step(mel, lab).item()
+        torch.cuda.synchronize()
+        for k in env:
+            monkeypatch.delenv(k)
+        return loss, m.flat.G.clone(), tr
+
+    l0, g0, tr0 = grads()
+    assert tr0.engine.tn_group is not None and tr0.engine.tn_group.last_info.n_items > 0          # the grouped launch ran
+    l1, g1, _ = grads(MRMT3_GEGLU_FUSED="0")
+    assert abs(l0 - l1) < 2e-6 and torch.equal(g0, g1)
+    l2, g2, tr2 = grads(MRMT3_TN_GROUP="0")
+    assert tr2.engine.tn_group is None
+    rel = ((g0 - g2).norm() / g2.norm()).item()
+    assert abs(l0 - l2) < 2e-6 and rel < 2e-6, rel
+    assert (g0 - g2).abs().max().item() < 1e-5 * g2.abs().max().item() + 1e-7
