@@ -58,9 +58,9 @@ class Engine:
         # dtype of sublayer outputs / dgrad outputs entering the fp32 residual add: the compute dtype
         # (bf16 halves that stream's HBM traffic; the residual itself and all statistics stay fp32)
         self.y_dtype = compute_dtype
-        # weight-gradient GEMMs are off the critical dgrad chain: they run on a second HIP stream and
-        # overlap the attention / dgrad kernels of the layers below (their outputs are only needed by
-        # the optimizer / the gradient exchange)
+        # weight-gradient GEMMs are off the critical dgrad chain (their outputs are only needed by the optimizer / the
+        # gradient exchange): the shapes the grouped kernel takes are deferred to join_wgrad() (tn_group below); the
+        # others run one by one on a second HIP stream and overlap the attention / dgrad kernels of the layers below
         self.overlap_wgrad = os.environ.get("MRMT3_WGRAD_STREAM", "1") != "0"
         # residual-stream GRADIENT of the bf16 path: bf16 between the norm-backward sites of a stack (f32 at both
         # ends) halves the largest streams of the backward row kernels; the forward residual stays f32
@@ -103,10 +103,11 @@ class Engine:
         return self._side
 
     def wgrad(self, a, b, out):
-        """out += a^T @ b on the side stream (inputs were produced on the current stream).  Kept cheap on the
-        host (45 calls per step): events come from a small ring, the kernel is launched on the side stream
-        directly, and the operands are kept alive by reference until the next join instead of
-        `record_stream` bookkeeping."""
+        """out += a^T @ b, complete after the next join_wgrad() (inputs were produced on the current stream).
+        Grouped path: only recorded here (operands kept alive), launched with every other gradient that is due.
+        One-by-one path (shapes the grouped kernel does not take): on the side stream, kept cheap on the host — events
+        come from a small ring, the kernel is launched on the side stream directly, and the operands are kept alive by
+        reference until the next join instead of `record_stream` bookkeeping."""
         if self.tn_group is not None and self.tn_group.ok(a, b, out):
             return self.tn_group.add(a, b, out, accumulate=True)
         if not self.overlap_wgrad:
