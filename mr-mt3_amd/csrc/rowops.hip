@@ -257,6 +257,13 @@ __device__ __forceinline__ void dw_reduce_body(const float* __restrict__ part, f
   // hand-off to the last-arriving chunk without __threadfence(): on gfx950 that is a write-back + invalidate of the
   // XCD's whole L2 per workgroup (5376 of them in the batched launch: 500-900 us for 168 MB).  Agent-scope relaxed
   // atomics (sc1: written through / read around the L2 per instruction), stores complete before the barrier.
+  // This is NOT a release/acquire pair in the HIP memory model: it leans on gfx950 behaviour — an
+  // acknowledged sc1 store (s_waitcnt vmcnt(0)) is visible to every later sc1 load of the device, and the inline-asm
+  // wait is a compiler barrier — hence the architecture check below; profiles/tools/norm_dw_stress.py is the stress
+  // test (900 iterations x 20 sites, alone and beside a second process: every result bit-identical).
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "dw_reduce_body's fence-free hand-off is validated on gfx950 only"
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
