@@ -298,6 +298,11 @@ def main():
         "graph_segments": (len(next(iter(trainer._graphs.values())).segments) + 1) if trainer._graphs else 0,
         "collectives": ("rccl, %d buckets per step%s" % (len(trainer.buckets.buckets), " (forced at world 1)" if force_coll and world == 1 else "")
                         if trainer.buckets.active else "none (world 1)"),
+        # the grouped weight-gradient launch of the last join (with collectives: of the last gradient bucket)
+        "weight_gradient_launch": (lambda g: None if g is None or g.last_info is None else
+                                   {"items": int(g.last_info.n_items), "gradient_tiles": int(g.last_info.n_rtiles),
+                                    "items_per_workgroup_max": int(g.last_info.rounds), "workgroups": int(g.last_info.n_ctas),
+                                    "partial_tile_bytes": int(g.last_info.slab_bytes)})(trainer.engine.tn_group),
         "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
         "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
