@@ -51,6 +51,23 @@ const char* mrmt3_last_error(void);
 void* mrmt3_host_alloc(size_t bytes);
 void mrmt3_host_free(void* p);
 
+/* Diagnostics: launches per kernel family since the process started (or since the last call with reset != 0).
+ * Writes min(n, MRMT3_CNT_N) counters to out and returns MRMT3_CNT_N.  Tests use it to assert that a shape really
+ * dispatched to the kernel they mean to check (e.g. the tall-shape ping-pong GEMM needs >= 4096 rows). */
+#define MRMT3_CNT_GEMM_NT_TILE 0      /* round-1 256x256 / 256x128 tile kernels (bf16 or exact f32) */
+#define MRMT3_CNT_GEMM_NT8 1          /* ping-pong NT kernel */
+#define MRMT3_CNT_GEMM_NT_GEGLU 2     /* fused wi + gated-GELU launches (not the two-kernel fallback) */
+#define MRMT3_CNT_TN_GROUP 3          /* grouped weight-gradient launches */
+#define MRMT3_CNT_TN8 4               /* one-gradient ping-pong TN launches */
+#define MRMT3_CNT_TN_TILE 5           /* round-1 128x128 TN kernel */
+#define MRMT3_CNT_ATTN_FWD 6          /* bf16 flash forward */
+#define MRMT3_CNT_ATTN_BWD 7          /* bf16 flash backward (two-pass: dQ, then dK/dV) */
+#define MRMT3_CNT_ATTN_BWD_ONEPASS 8  /* bf16 one-pass backward (keys of a (batch, head) owned by one workgroup) */
+#define MRMT3_CNT_ATTN_F32 9          /* exact-f32 attention kernels */
+#define MRMT3_CNT_TN_F32 10           /* exact-f32 weight-gradient kernel */
+#define MRMT3_CNT_N 11
+int mrmt3_dispatch_counts(unsigned long long* out, int n, int reset);
+
 /* ---- K1: log-mel frontend ---------------------------------------------------------------------
  * contrib/spectrograms.py:92-103,128-145 (pad_end, MelSpectrogram(n_fft 2048, hop, power 1,
  * center False), safe_log) + dataset/dataset_2_random.py:288-289 (clip/scale when normalize!=0)

@@ -1,6 +1,8 @@
 // Library-level entry points: version and thread-local error text.
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -28,4 +30,21 @@ extern "C" void* mrmt3_host_alloc(size_t bytes) {
 }
 extern "C" void mrmt3_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+
+// Diagnostics only: how often each kernel family was launched by this process (tests assert that a shape really
+// dispatched to the kernel they mean to check).  Relaxed atomics; no effect on any result.
+static std::atomic<unsigned long long> g_counts[MRMT3_CNT_N];
+void mrmt3_count(int which) {
+  if (which >= 0 && which < MRMT3_CNT_N) g_counts[which].fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" int mrmt3_dispatch_counts(unsigned long long* out, int n, int reset) {
+  if (out == nullptr || n < 0) {
+    mrmt3_set_error("dispatch_counts: bad arguments");
+    return -1;
+  }
+  for (int i = 0; i < n && i < MRMT3_CNT_N; ++i)
+    out[i] = reset ? g_counts[i].exchange(0, std::memory_order_relaxed) : g_counts[i].load(std::memory_order_relaxed);
+  for (int i = MRMT3_CNT_N; i < n; ++i) out[i] = 0;
+  return MRMT3_CNT_N;
 }

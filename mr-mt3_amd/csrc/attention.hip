@@ -41,14 +41,19 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
   return r;
 }
 
-// attention-probability dropout.  Element (q,k) of head-matrix bh belongs to the 2x2 group
-// (q>>1, k>>1); one 32-bit mix per group yields four 8-bit lanes, byte ((q&1)<<1 | (k&1)) decides
-// the element.  Every kernel layout (4 consecutive keys per lane in forward/dQ, 4 consecutive
-// queries per lane in dK/dV) therefore needs 2 mixes per 4 elements.  The drop probability is
-// quantised to thresh8/256 (p=0.1 -> 26/256) and the keep scale is 256/(256-thresh8), so forward
-// and backward stay exactly consistent and unbiased.  The kernels only ZERO the dropped probabilities
-// in the loop; the constant keep scale is applied once to the accumulated O / dV (and inside the
-// fused multiply-add that forms dS), which takes a multiply per element out of the inner loop.
+// attention-probability dropout.  Element (q,k) of head-matrix bh takes byte (k & 3) of the 32-bit word
+// W(bh, q, k >> 2) = mix24(seed + bh*CB + q*CQ + (k >> 2)*CK): one mix per query row and group of four consecutive keys.
+// Forward and dQ hold exactly such a group per lane and accumulator tile (query on the lane, keys 4g..4g+3 in the four
+// registers): ONE mix per 4 elements, the lane's part of the argument is loop-invariant and the key tile's part a scalar.
+// dK/dV hold the transposed group (key on the lane, four consecutive queries): the four lanes of a quad hold the same
+// four queries for keys 4g..4g+3, so each computes the word of ONE query and reads the other three through DPP
+// quad-permutes (a v_and with the lane's byte mask as the DPP instruction, then a compare with the threshold shifted into
+// that byte).  Round 2 used 2x2 groups — two mixes per 4 elements in every layout — and the mask was 42-53 % of the
+// kernels' vector instructions (profiles/r03_attn_isa_mix.txt).  The drop probability is quantised to thresh8/256
+// (p=0.1 -> 26/256) and the keep scale is 256/(256-thresh8), so forward and backward stay exactly consistent and
+// unbiased.  The kernels only ZERO the dropped probabilities in the loop; the constant keep scale is applied once to
+// the accumulated O / dV (and inside the fused multiply-add that forms dS).  oracle/dropout_ref.attn_keep_mask restates
+// the generator; tests compare the kernels' kept sets with it bit for bit and check its statistics on the CPU.
 struct AttnDrop {
   const int* step;   // nullable device step counter (see DropCfg::step)
   unsigned seed;
@@ -78,9 +83,14 @@ __device__ __forceinline__ unsigned mix24(unsigned x) {
   x ^= x >> 16; x = __umul24(x, 0x7feb35u); x ^= x >> 15; x = __umul24(x, 0x6ca68bu);
   return x;
 }
-// `g` is the group's mix already shifted so that this lane's two elements sit in bytes `byte` (0..3, constant)
+// byte `byte` (0..3, a compile-time constant: an SDWA byte select on the compare) of the group's word decides element `byte`
 __device__ __forceinline__ float drop_sel(const AttnDrop& d, unsigned g, int byte, float v) {
   return ((g >> (8 * byte)) & 0xFFu) >= d.thresh8 ? v : 0.f;
+}
+// dK/dV layout: word of query r of the lane's quad, fetched from the lane that computed it (quad_perm [r,r,r,r])
+template <int R>
+__device__ __forceinline__ unsigned quad_word(unsigned w) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)w, R * 0x55, 0xF, 0xF, true);
 }
 // max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): gfx950's v_permlane16/32_swap are
 // plain VALU moves, so the reduction has no LDS (ds_bpermute) round trip in the softmax's dependency chain
@@ -198,9 +208,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   // Q fragments (B operand): lane holds Q[q = qrow(qt)][d = 32ks + 8g .. +7]
   bf16x8 qf[2][2];
   int qrow[2];
+  unsigned drop_q[2];     // the lane's part of the mask argument: head, query row, key group 4g..4g+3 inside a 16-key tile
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     qrow[qt] = q0 + uw * 32 + qt * 16 + fr;
+    drop_q[qt] = drop_bh + (unsigned)qrow[qt] * DROP_CQ + (unsigned)fg * DROP_CK;
     const int r = min(qrow[qt], P.Lq - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *(const bf16x8*)(qb + (size_t)r * P.ldq + ks * 32 + fg * 8);
@@ -241,9 +253,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     const unsigned char* lv = lk + 8192;
     cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
 
-    // causal: a tile that lies entirely above this wave's 32 query rows contributes nothing
-    const bool wave_active = !(P.causal && kv0 > q0 + uw * 32 + 31);
-    if (wave_active) {
+    // (causal: the last key tile of a query tile lies entirely above the 32 rows of waves 0 and 1.  They run it anyway,
+    // fully masked: a per-wave skip made the accumulators loop-carried through two paths and hipcc copied all of them
+    // at every back-edge — 72 v_mov per tile, 16 % of the loop's vector instructions — while the skipped waves only
+    // waited at the next barrier.)
     // S^T = K . Q^T : sT[qt][kt] holds S^T[key = kt*16 + 4g + r][q = fr]
     f32x4 sT[2][4];
 #pragma unroll
@@ -299,16 +312,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
       // basic block the mask code keeps its registers to itself (164 VGPRs, no spill); merged into the exp loop by the
       // scheduler the kernel spills and is 12% slower.
       if (DROP && P.drop.thresh8) {
-        const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
-        const unsigned sh = (qrow[qt] & 1) << 4;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-          const unsigned kp = (unsigned)(kv0 + kt * 16 + fg * 4) >> 1;
-          const unsigned g0 = mix24(qb_ + kp * DROP_CK) >> sh, g1 = mix24(qb_ + (kp + 1) * DROP_CK) >> sh;
-          sT[qt][kt][0] = drop_sel(P.drop, g0, 0, sT[qt][kt][0]);
-          sT[qt][kt][1] = drop_sel(P.drop, g0, 1, sT[qt][kt][1]);
-          sT[qt][kt][2] = drop_sel(P.drop, g1, 0, sT[qt][kt][2]);
-          sT[qt][kt][3] = drop_sel(P.drop, g1, 1, sT[qt][kt][3]);
+          const unsigned g = mix24(drop_q[qt] + (unsigned)((kv0 >> 2) + kt * 4) * DROP_CK);   // scalar tile part
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sT[qt][kt][r] = drop_sel(P.drop, g, r, sT[qt][kt][r]);
         }
       }
     }
@@ -325,7 +333,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
         for (int qt = 0; qt < 2; ++qt) oT[qt][dt] = mfma16(vt, pb[qt], oT[qt][dt]);
       }
     }
-    }  // wave_active
   }
   VMCNT(0);      // the switched-off prefetches of the last two iterations still write their zeros
 
@@ -393,9 +400,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
 
   bf16x8 kf[2][2], vf[2][2];
   int key[2];
+  // mask: the lane computes the word of query (fg*4 + fp) of each 16-query tile for its key's group of four; its own
+  // element sits in byte (key & 3) = fp of every word of the quad
+  unsigned drop_k[2];
+  const unsigned drop_bmask = 0xFFu << (8 * fp), drop_bthr = P.drop.thresh8 << (8 * fp);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     key[nt] = k0 + uw * 32 + nt * 16 + fr;
+    drop_k[nt] = drop_bh + ((unsigned)key[nt] >> 2) * DROP_CK + (unsigned)(fg * 4 + fp) * DROP_CQ;
     const int r = min(key[nt], P.Lk - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -474,14 +486,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
         }
         float pk[4] = {pv[0], pv[1], pv[2], pv[3]}, dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
         if (DROP && P.drop.thresh8) {    // run-time test on purpose, see the forward kernel
-          const unsigned qp = (unsigned)(qb0 + qt * 16 + fg * 4) >> 1;
-          const unsigned kb_ = drop_bh + ((unsigned)key[nt] >> 1) * DROP_CK;
-          const unsigned sh = (key[nt] & 1) << 3;
-          const unsigned g0 = mix24(kb_ + qp * DROP_CQ) >> sh, g1 = mix24(kb_ + (qp + 1) * DROP_CQ) >> sh;
-          pk[0] = drop_sel(P.drop, g0, 0, pk[0]); dk_[0] = drop_sel(P.drop, g0, 0, dk_[0]);
-          pk[1] = drop_sel(P.drop, g0, 2, pk[1]); dk_[1] = drop_sel(P.drop, g0, 2, dk_[1]);
-          pk[2] = drop_sel(P.drop, g1, 0, pk[2]); dk_[2] = drop_sel(P.drop, g1, 0, dk_[2]);
-          pk[3] = drop_sel(P.drop, g1, 2, pk[3]); dk_[3] = drop_sel(P.drop, g1, 2, dk_[3]);
+          // this lane's word: query (fp-th of its quad's four), key group key >> 2; the quad's other three by DPP
+          const unsigned w = mix24(drop_k[nt] + (unsigned)(qb0 + qt * 16) * DROP_CQ);
+          const bool k0_ = (quad_word<0>(w) & drop_bmask) >= drop_bthr, k1_ = (quad_word<1>(w) & drop_bmask) >= drop_bthr;
+          const bool k2_ = (quad_word<2>(w) & drop_bmask) >= drop_bthr, k3_ = (quad_word<3>(w) & drop_bmask) >= drop_bthr;
+          pk[0] = k0_ ? pk[0] : 0.f; dk_[0] = k0_ ? dk_[0] : 0.f;
+          pk[1] = k1_ ? pk[1] : 0.f; dk_[1] = k1_ ? dk_[1] : 0.f;
+          pk[2] = k2_ ? pk[2] : 0.f; dk_[2] = k2_ ? dk_[2] : 0.f;
+          pk[3] = k3_ ? pk[3] : 0.f; dk_[3] = k3_ ? dk_[3] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -556,10 +568,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
 
   bf16x8 qf[2][2], dof[2][2];
   int qrow[2];
+  unsigned drop_q[2];
   float lse_q[2], dlt_q[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     qrow[qt] = q0 + uw * 32 + qt * 16 + fr;
+    drop_q[qt] = drop_bh + (unsigned)qrow[qt] * DROP_CQ + (unsigned)fg * DROP_CK;
     const int r = min(qrow[qt], P.Lq - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -617,8 +631,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     const unsigned char* lk = lds + cur * KV_STAGE_BYTES;
     const unsigned char* lv = lk + 8192;
     cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
-    const bool wave_active = !(P.causal && kv0 > q0 + uw * 32 + 31);
-    if (wave_active) {
+    // (no per-wave skip of the fully masked last causal tile: see the forward kernel)
     const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * 32);
     f32x4 dsT[2][4];  // [qt][kt] : dS^T[key = kt*16+4g+r][q = fr]
 #pragma unroll
@@ -646,14 +659,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
         }
         float dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
         if (DROP && P.drop.thresh8) {    // run-time test on purpose, see the forward kernel
-          const unsigned qb_ = drop_bh + ((unsigned)qrow[qt] >> 1) * DROP_CQ;
-          const unsigned sh = (qrow[qt] & 1) << 4;
-          const unsigned kpi = (unsigned)(kv0 + kt * 16 + fg * 4) >> 1;
-          const unsigned g0 = mix24(qb_ + kpi * DROP_CK) >> sh, g1 = mix24(qb_ + (kpi + 1) * DROP_CK) >> sh;
-          dk_[0] = drop_sel(P.drop, g0, 0, dk_[0]);
-          dk_[1] = drop_sel(P.drop, g0, 1, dk_[1]);
-          dk_[2] = drop_sel(P.drop, g1, 0, dk_[2]);
-          dk_[3] = drop_sel(P.drop, g1, 1, dk_[3]);
+          const unsigned g = mix24(drop_q[qt] + (unsigned)((kv0 >> 2) + kt * 4) * DROP_CK);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dk_[r] = drop_sel(P.drop, g, r, dk_[r]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) dsT[qt][kt][r] = pv[r] * fmaf(dk_[r], P.drop.scale, -dlt_q[qt]);
@@ -671,7 +679,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
         for (int qt = 0; qt < 2; ++qt) dqT[qt][dt] = mfma16(kt_, db[qt], dqT[qt][dt]);
       }
     }
-    }  // wave_active
   }
   VMCNT(0);
 #pragma unroll
@@ -758,6 +765,7 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
     hipLaunchKernelGGL(attn_f32_kernel, dim3(Lq, H, B), dim3(256), shm, s, (const float*)q, ldq, (const float*)k, ldk,
                        (const float*)v, ldv, (float*)o, ldo, lse, H, Lq, Lk, causal);
     MR_CHECK_LAUNCH("attn_fwd f32");
+    mrmt3_count(MRMT3_CNT_ATTN_F32);
     return MRMT3_OK;
   }
   MR_CHECK_ARG(dtype == MRMT3_BF16, "attn_fwd: unknown dtype");
@@ -775,6 +783,7 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   else if (P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_fwd");
+  mrmt3_count(MRMT3_CNT_ATTN_FWD);
   return MRMT3_OK;
 }
 
@@ -809,5 +818,6 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   else if (drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, true>), gk, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, false>), gk, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dkdv");
+  mrmt3_count(MRMT3_CNT_ATTN_BWD);
   return MRMT3_OK;
 }

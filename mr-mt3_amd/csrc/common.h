@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // ---- error plumbing (never abort / throw across the C ABI) --------------------------------------
 void mrmt3_set_error(const char* fmt, ...);
+void mrmt3_count(int which);   // diagnostics: launches per kernel family (MRMT3_CNT_*), read by mrmt3_dispatch_counts
 #define MR_CHECK_ARG(cond, ...)                      \
   do {                                               \
     if (!(cond)) {                                   \

@@ -255,6 +255,7 @@ static int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, in
     if (use_gemm8() && mrmt3_gemm_nt8_try(A, lda, B, ldb, C, ldc, M, N, K, sizeof(TOUT) == 2 ? MRMT3_BF16 : MRMT3_F32,
                                            ACCUM ? 1 : 0, s)) {
       MR_CHECK_LAUNCH("gemm_nt8");
+      mrmt3_count(MRMT3_CNT_GEMM_NT8);
       return MRMT3_OK;
     }
   }
@@ -268,6 +269,7 @@ static int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, in
                        (const TIN*)A, lda, (const TIN*)B, ldb, (TOUT*)C, ldc, M, N, K, tiles_n);
   }
   MR_CHECK_LAUNCH("gemm_nt");
+  mrmt3_count(MRMT3_CNT_GEMM_NT_TILE);
   return MRMT3_OK;
 }
 
@@ -562,6 +564,7 @@ extern "C" int mrmt3_gemm_tn_partial(const void* A, int lda, const void* B, int 
     if (use_tn8(M, N1, N2, &t8, &s8, &r8)) {
       mrmt3_tn8_launch(A, lda, B, ldb, (float*)slabs, M, N1, N2, t8, s8, r8, (hipStream_t)stream);
       MR_CHECK_LAUNCH("gemm_tn8");
+      mrmt3_count(MRMT3_CNT_TN8);
       return MRMT3_OK;
     }
   }
@@ -569,6 +572,7 @@ extern "C" int mrmt3_gemm_tn_partial(const void* A, int lda, const void* B, int 
                      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)slabs, M, N1, N2, ceil_div(N2, TILE), tiles,
                      splits, rps);
   MR_CHECK_LAUNCH("gemm_tn_partial");
+  mrmt3_count(MRMT3_CNT_TN_TILE);
   return MRMT3_OK;
 }
 
@@ -594,7 +598,9 @@ extern "C" int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, flo
   int t8, s8, r8;
   if (use_tn8(M, N1, N2, &t8, &s8, &r8)) {
     mrmt3_tn8_launch(A, lda, B, ldb, (float*)workspace, M, N1, N2, t8, s8, r8, s);
+    mrmt3_count(MRMT3_CNT_TN8);
   } else {
+    mrmt3_count(MRMT3_CNT_TN_TILE);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((tiles * splits + 7) & ~7)), dim3(256), 0, s, (const bf16_t*)A, lda,
                        (const bf16_t*)B, ldb, (float*)workspace, M, N1, N2, ceil_div(N2, TILE), tiles, splits, rps);
   }

@@ -554,5 +554,6 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
   if (small) hipLaunchKernelGGL((gemm_nt8_kernel<bf16_t, false, 4, 1>), dim3((unsigned)grid), dim3(512), 0, s, P);
   else hipLaunchKernelGGL((gemm_nt8_kernel<bf16_t, false, 8, 1>), dim3((unsigned)grid), dim3(512), 0, s, P);
   MR_CHECK_LAUNCH("gemm_nt_geglu");
+  mrmt3_count(MRMT3_CNT_GEMM_NT_GEGLU);
   return MRMT3_OK;
 }

@@ -629,5 +629,6 @@ extern "C" int mrmt3_tn_group_run(void* table_dev, const void* table_host, const
   hipLaunchKernelGGL(tn8_group_reduce_kernel, dim3((unsigned)info->n_rtiles * 64u), dim3(256), 0, s,
                      (const T8RTile*)((const char*)table_dev + info->rtile_offset));
   MR_CHECK_LAUNCH("tn_group_run reduce");
+  mrmt3_count(MRMT3_CNT_TN_GROUP);
   return MRMT3_OK;
 }

@@ -145,6 +145,20 @@ class Engine:
         if self.tn_group is not None:
             self.tn_group.flush()        # the deferred weight gradients: their operands were produced on this stream
 
+    def reset_deferred(self):
+        """Forget every deferred launch: the weight gradients recorded for the grouped launch, the queued split-K slab
+        and norm-weight reductions, the operands held for the side stream.  After an aborted hipGraph capture (or an
+        exception in the middle of a backward pass) these still name tensors of work that never ran — a later flush
+        would accumulate uninitialised memory into the gradients."""
+        if self.tn_group is not None:
+            self.tn_group._sites.clear()
+        if self.tn_batch is not None:
+            self.tn_batch._queue.clear()
+        if self.norm_dw is not None:
+            self.norm_dw._queue.clear()
+        self._held.clear()
+        self._side_dirty = False
+
     def prepare(self, training: bool):
         if self.dt == torch.bfloat16:
             self.flat.refresh_shadows(need_transposed=training)

@@ -48,6 +48,7 @@ _SIGS = {
     "mrmt3_tn_group_run": (ci, [vp, vp, vp, vp]),
     "mrmt3_host_alloc": (vp, [C.c_size_t]),
     "mrmt3_host_free": (None, [vp]),
+    "mrmt3_dispatch_counts": (ci, [vp, ci, ci]),
     "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_bwd_workspace_bytes": (csz, [ci, ci, ci]),
@@ -103,6 +104,18 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
+                 "attn_bwd_onepass", "attn_f32", "tn_f32")
+
+
+def dispatch_counts(reset: bool = False) -> dict:
+    """Launches per kernel family since the process started / the last reset (mrmt3_dispatch_counts; diagnostics)."""
+    arr = (C.c_ulonglong * len(COUNTER_NAMES))()
+    n = load().mrmt3_dispatch_counts(arr, len(COUNTER_NAMES), int(reset))
+    assert n == len(COUNTER_NAMES), "lib.COUNTER_NAMES is out of step with MRMT3_CNT_N"
+    return {k: int(arr[i]) for i, k in enumerate(COUNTER_NAMES)}
 
 
 # Optional per-launch timing used by bench.py's roofline leg: when PROFILE is a list, the wrappers of
@@ -244,6 +257,8 @@ class TnBatch:
 
     def site(self, out, M, N1, N2, accumulate):
         key = (out.data_ptr(), M, N1, N2, out.stride(0), int(accumulate))
+        if key in self._queue:
+            self.flush()               # the same gradient twice before a flush: its slab buffer is still waiting to be summed
         buf = self._slabs.get(key)
         if buf is None:
             buf = torch.empty(load().mrmt3_gemm_tn_workspace_bytes(M, N1, N2), device=out.device, dtype=torch.uint8)
@@ -269,8 +284,10 @@ class TnBatch:
                 blocks += -(-(N1 * N2) // 1024)
             tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(self._dev), len(keys), blocks)
             self._tables[keys] = tab
-        _check(load().mrmt3_tn_reduce_sites(_p(tab[0]), tab[1], tab[2], _stream()), "tn_reduce_sites")
-        self._queue.clear()
+        try:
+            _check(load().mrmt3_tn_reduce_sites(_p(tab[0]), tab[1], tab[2], _stream()), "tn_reduce_sites")
+        finally:
+            self._queue.clear()
 
 
 class _TnGSite(C.Structure):          # = mrmt3_tn_gsite
@@ -327,6 +344,10 @@ class TnGroup:
 
     def add(self, a, b, out, accumulate=True):
         assert a.shape[0] == b.shape[0] and tuple(out.shape) == (a.shape[1], b.shape[1])
+        if any(o.data_ptr() == out.data_ptr() for _, _, o, _ in self._sites):
+            # the same gradient twice in one launch (a weight used twice per backward): its tiles would be reduced into
+            # C by different workgroups without an order.  Finish the first use before the second is queued.
+            self.flush()
         self._sites.append((a, b, out, int(bool(accumulate))))
 
     def __len__(self):
@@ -344,6 +365,12 @@ class TnGroup:
     def flush(self):
         if not self._sites:
             return
+        try:
+            self._flush()
+        finally:
+            self._sites.clear()        # also when planning / launching raised: the sites must not leak into the next flush
+
+    def _flush(self):
         L = load()
         dev = self._sites[0][0].device
         key = tuple((a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), o.data_ptr(), o.stride(0), a.shape[0],
@@ -389,7 +416,6 @@ class TnGroup:
             _check(L.mrmt3_tn_group_run(_p(ent["table"]), C.c_void_p(ent["host"].ptr), C.byref(ent["info"]), _stream()),
                    "tn_group_run")
         self.last_info = ent["info"]
-        self._sites.clear()
 
 
 def gemm_tn(a, b, out, accumulate=False, stream=None, defer=None):

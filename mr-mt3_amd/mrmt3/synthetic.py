@@ -130,6 +130,17 @@ def synth_labels(batch: int, length: int = 1024, seed: int = 365, full: bool = T
     return lab
 
 
+def bench_shape_inputs(batch: int = 16, length: int = 1024, seed: int = 4242):
+    """Inputs of the bench-shaped parity tests (decoder rows = batch * 1024 >= 16384, encoder rows >= 4096, i.e. the
+    shapes at which the tall-GEMM, fused wi+GEGLU and grouped weight-gradient kernels dispatch): mel, labels with even
+    rows full-length and odd rows Slakh-shaped (EOS then -100 padding), and an independent targets_prev stream."""
+    mel = synth_mel(batch, seed=seed)
+    lab = synth_labels(batch, length, seed=seed + 1, full=False, mean_len=500)
+    lab[::2] = synth_labels(batch, length, seed=seed + 2, full=True)[::2]
+    prev = synth_labels(batch, length, seed=seed + 3, full=False, mean_len=500)
+    return mel, lab, prev
+
+
 def sinusoid_table(n_pos: int, dim: int):
     """`FixedPositionalEmbedding`, reference `models/t5.py:705-719`: [sin | cos] halves (not
     interleaved).  Computed with torch CPU fp32 ops in the reference's own op order so the table

@@ -83,6 +83,7 @@ class Trainer:
         """Enqueues one optimizer step.  `cut(bucket_indices)` is called where a gradient bucket is complete (only
         when collectives will run); under capture it closes the current graph segment."""
         eng, flat = self.engine, self.flat
+        eng.reset_deferred()                                 # nothing of an aborted capture / failed step leaks into this one
         eng._stream_ctr = 0                                  # dropout site ids are per-step (step_dev salts them)
         mel = self.mel_from_audio(inputs) if audio else inputs
         dec, tape = eng.forward(mel, labels, targets_prev, training=True, need_grad=True, want_logits=False)
@@ -144,7 +145,8 @@ class Trainer:
             try:
                 cap = self._capture(sig, inputs, labels, targets_prev, audio)
             except Exception as e:     # noqa: BLE001 — whatever a capture trips over, the eager step is still correct
-                # (nothing executed during the failed capture: the step below is the first to run)
+                # (nothing executed during the failed capture: the step below is the first to run; the launches the
+                # aborted capture had deferred are dropped — _step_body starts with Engine.reset_deferred())
                 import warnings
                 warnings.warn("hipGraph capture of the training step failed (%s: %s); continuing with eager launches"
                               % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))

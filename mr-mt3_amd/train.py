@@ -50,9 +50,14 @@ def synthetic_batches(cfg, rank, device, steps, with_prev):
         yield audio, labels, prev
 
 
-def real_loaders(cfg):
+def real_loaders(cfg, world=1, rank=0):
     """DataLoaders over the configured datasets (train.py:48-59).  Raises with a clear message when the dataset
-    package (the reference's `dataset/`, not part of this path) cannot be imported."""
+    package (the reference's `dataset/`, not part of this path) cannot be imported.
+
+    With more than one rank each loader gets a `DistributedSampler` — what Lightning's DDP strategy injects into the
+    reference's plain DataLoaders (`pl.Trainer(strategy="ddp...")`, config/config.yaml:45): every rank iterates a
+    disjoint 1/world shard, an epoch is len(dataset)/world steps (which is what `optim.num_steps_per_epoch` counts)
+    and the effective batch is world x the per-rank batch.  Returns (train_loader, val_loader, train_sampler or None)."""
     from torch.utils.data import DataLoader
     try:
         train_set = hydra_lite.instantiate(cfg.dataset.train)
@@ -65,13 +70,24 @@ def real_loaders(cfg):
             "to run synthetic Slakh-shaped batches.") from e
     kw_t = {k: v for k, v in dict(cfg.dataloader.train).items()}
     kw_v = {k: v for k, v in dict(cfg.dataloader.val).items()}
-    return (DataLoader(train_set, collate_fn=collate, **kw_t), DataLoader(val_set, collate_fn=collate, **kw_v))
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=bool(kw_t.pop("shuffle", False)),
+                                     seed=int(cfg.seed))
+        kw_t["sampler"] = sampler
+        kw_v.pop("shuffle", None)
+        kw_v["sampler"] = DistributedSampler(val_set, num_replicas=world, rank=rank, shuffle=False)
+    return (DataLoader(train_set, collate_fn=collate, **kw_t), DataLoader(val_set, collate_fn=collate, **kw_v), sampler)
 
 
-def loader_batches(loader, device, epochs, max_steps):
-    """(epoch, inputs, targets, targets_prev) from the reference's collated batches, moved to the device."""
-    n = 0
-    for ep in range(epochs):
+def loader_batches(loader, device, epochs, max_steps, start_epoch=0, start_step=0, sampler=None):
+    """(epoch, inputs, targets, targets_prev) from the reference's collated batches, moved to the device.  A resumed
+    run continues at (start_epoch, start_step): `max_steps` counts global steps, like Lightning's."""
+    n = start_step
+    for ep in range(start_epoch, epochs):
+        if sampler is not None:
+            sampler.set_epoch(ep)            # a different shuffle per epoch, the same one on every rank
         for batch in loader:
             if max_steps is not None and n >= max_steps:
                 return
@@ -108,27 +124,34 @@ def main(argv=None):
                                                      min_lr=float(cfg.optim.min_lr))
     trainer = Trainer(task.model, lr=float(cfg.optim.lr), lr_lambda=lam,
                       weighted_loss=type(task).__name__ == "MT3NetWeightedLoss")
+    task.model.engine.seed = int(cfg.seed)
     with_prev = "WithPrev" in type(task).__name__
     synthetic = bool(cfg.get("synthetic", False))
     max_steps = cfg.get("max_steps")
     max_steps = None if max_steps is None else int(max_steps)
-    train_loader = val_loader = None
+    train_loader = val_loader = sampler = None
     if not synthetic:
-        train_loader, val_loader = real_loaders(cfg)
-    start = 0
+        train_loader, val_loader, sampler = real_loaders(cfg, world, rank)
+    start, start_epoch, resumed = 0, 0, False
     path = cfg.get("path")
     if path is not None and str(path) != "":
         path = str(path)
         if path.endswith(".ckpt"):
             start = trainer.resume(path)
+            from mrmt3 import checkpoint as ck
+            start_epoch = int(ck.read_checkpoint(path).get("epoch", 0) or 0)
             if rank == 0:
-                print(f"Resuming from {path} at step {start}", flush=True)
+                print(f"Resuming from {path} at step {start}, epoch {start_epoch}", flush=True)
         elif path.endswith(".pth"):
             if rank == 0:
                 print(f"Loading weights from {path}...", flush=True)
             trainer.resume(path)
         else:
             raise ValueError(f"Invalid extension for path: {path}")
+        resumed = True
+    # every rank draws its own dropout masks (torch DDP: one generator per process), not world copies of one mask
+    # (after the resume, which restores the seed rank 0 saved)
+    task.model.engine.seed += 1000003 * rank
     log_every = max(1, int(cfg.trainer.get("log_every_n_steps", 100)))
     if synthetic:
         steps = 10 if max_steps is None else max_steps
@@ -138,26 +161,35 @@ def main(argv=None):
                 print(f"step {it} train_loss {loss.item():.4f}", flush=True)
     else:
         val_every = max(1, int(cfg.trainer.get("check_val_every_n_epoch", 1)))
-        it, last_ep, loss = start, 0, None
+        it, last_ep, loss = start, start_epoch, None
 
         def validate(ep):
-            tot, n = 0.0, 0
+            """val_loss = mean over the batches of ALL ranks (each rank holds a shard of the validation set)."""
+            acc = torch.zeros(2, device=device, dtype=torch.float64)
             for b in val_loader:
                 prev = b[2].to(device) if len(b) > 2 else None
-                tot += float(trainer.eval_loss(b[0].to(device), b[1].to(device), prev).item())
-                n += 1
-            if rank == 0 and n:
-                print(f"epoch {ep} val_loss {tot / n:.4f}", flush=True)
+                acc[0] += trainer.eval_loss(b[0].to(device), b[1].to(device), prev).double().sum()
+                acc[1] += 1
+            if world > 1:
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            if rank == 0 and acc[1].item() > 0:
+                print(f"epoch {ep} val_loss {(acc[0] / acc[1]).item():.4f}", flush=True)
 
-        for ep, mel, labels, prev in loader_batches(train_loader, device, int(cfg.num_epochs), max_steps):
-            if ep != last_ep and ep % val_every == 0:
+        if resumed:
+            validate(start_epoch)        # the reference validates the loaded weights before fit (train.py:61-87)
+        for ep, mel, labels, prev in loader_batches(train_loader, device, int(cfg.num_epochs), max_steps,
+                                                    start_epoch, start, sampler):
+            if ep != last_ep and (last_ep + 1) % val_every == 0:
                 validate(last_ep)
             last_ep = ep
             loss = trainer.train_step(mel, labels, prev, audio=False)
             if rank == 0 and it % log_every == 0:
                 print(f"step {it} train_loss {loss.item():.4f}", flush=True)
             it += 1
-        validate(last_ep)
+        if rank == 0 and loss is not None and (it - 1) % log_every != 0:
+            print(f"step {it - 1} train_loss {loss.item():.4f}", flush=True)
+        if (last_ep + 1) % val_every == 0:
+            validate(last_ep)
     if rank == 0:
         out_dir = os.path.join(str(cfg.get("output_dir", ".")), f"{cfg.model_type}_{cfg.dataset_type}",
                                "version_0", "checkpoints")

@@ -72,9 +72,9 @@ def _attn_mix24(x):
 
 
 def attn_keep_mask(B, H, Lq, Lk, p, seed, stream, step=None):
-    """-> (keep[B, H, Lq, Lk] bool, scale).  Element (q, k) of head-matrix (b, h) belongs to the 2x2 group
-    (q >> 1, k >> 1); one mix per group, byte ((q & 1) << 1 | (k & 1)) decides the element; keep iff byte >= thresh8
-    with thresh8 = round(256 p) and scale = 256 / (256 - thresh8)."""
+    """-> (keep[B, H, Lq, Lk] bool, scale).  Element (q, k) of head-matrix (b, h) takes byte (k & 3) of the word
+    mix24(seed' + bh * CB + q * CQ + (k >> 2) * CK): one mix per query row and group of four consecutive keys; keep iff
+    byte >= thresh8 with thresh8 = round(256 p) and scale = 256 / (256 - thresh8)  (csrc/attention.hip, round 3)."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     s32 = (((seed & 0xFFFFFFFF) ^ (seed >> 32)) + int(stream) * 0x27D4EB2F + step_salt(step)) & 0xFFFFFFFF
     if p <= 0.0:
@@ -84,7 +84,7 @@ def attn_keep_mask(B, H, Lq, Lk, p, seed, stream, step=None):
     bh = (np.arange(B * H, dtype=np.uint64) * np.uint64(0xC2B2AE35)).reshape(B, H, 1, 1)
     q = np.arange(Lq, dtype=np.uint64).reshape(1, 1, Lq, 1)
     k = np.arange(Lk, dtype=np.uint64).reshape(1, 1, 1, Lk)
-    x = (np.uint64(s32) + bh + (q >> np.uint64(1)) * np.uint64(0x9E3779B1) + (k >> np.uint64(1)) * np.uint64(0x85EBCA6B)) & M32
+    x = (np.uint64(s32) + bh + q * np.uint64(0x9E3779B1) + (k >> np.uint64(2)) * np.uint64(0x85EBCA6B)) & M32
     h = _attn_mix24(x)
-    byte = (h >> (np.uint64(8) * (((q & np.uint64(1)) << np.uint64(1)) | (k & np.uint64(1))))) & np.uint64(0xFF)
+    byte = (h >> (np.uint64(8) * (k & np.uint64(3)))) & np.uint64(0xFF)
     return byte >= np.uint64(t8), scale

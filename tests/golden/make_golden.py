@@ -120,6 +120,11 @@ def build_reference(variant: str, segmem_length: int = 64):
     return m
 
 
+def zlib_seed(name):
+    import zlib
+    return zlib.crc32(name.encode()) & 0x7FFFFFFF
+
+
 def sample_idx(shape, n, seed):
     rs = np.random.RandomState(seed)
     return rs.randint(0, int(np.prod(shape)), size=n)
@@ -134,6 +139,10 @@ def main():
     ap.add_argument("--bf16-bound", action="store_true",
                     help="only record what the REFERENCE itself loses under torch.autocast(bfloat16) vs its fp32 run "
                          "(tests/golden/bf16_bound.npz): the yardstick for the bf16 compute path's logit tolerance")
+    ap.add_argument("--bench-shape", action="store_true",
+                    help="only record the reference's fp32 loss / sampled logits / per-tensor gradient norms + samples, "
+                         "and its autocast deviations, at B=16 x 1024 tokens (tests/golden/bench_shape.npz): the shape "
+                         "at which the kernels the benchmark times dispatch")
     ap.add_argument("--v1-decode", action="store_true",
                     help="only add T5SegMem's generate / generate_2 outputs to the existing npz")
     args = ap.parse_args()
@@ -252,6 +261,60 @@ def main():
                 rels[w], names[w], min(coss), float(np.median(rels))), flush=True)
         np.savez_compressed(os.path.join(HERE, "bf16_bound.npz"), **rec)
         print("wrote bf16_bound.npz")
+        return
+    if args.bench_shape:
+        from mrmt3.synthetic import bench_shape_inputs
+        mel_b, lab_b, prev_b = (torch.from_numpy(a) for a in bench_shape_inputs())
+        rec = {}
+        for variant in ("t5", "segmem_v2_with_prev"):
+            m = build_reference(variant)
+            grads, logits = {}, {}
+            for mode in ("fp32", "autocast"):
+                t0 = time.time()
+                m.zero_grad(set_to_none=True)
+                kw = {"targets_prev": prev_b.clone()} if variant == "segmem_v2_with_prev" else {}
+                if mode == "autocast":
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        lg = m(inputs=mel_b, labels=lab_b, **kw).float()
+                else:
+                    lg = m(inputs=mel_b, labels=lab_b, **kw)
+                loss = F.cross_entropy(lg.view(-1, lg.shape[-1]), lab_b.view(-1), ignore_index=-100)
+                loss.backward()
+                grads[mode] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+                logits[mode] = lg.detach()
+                rec[f"{variant}.{mode}.loss"] = np.float64(F.cross_entropy(
+                    lg.detach().view(-1, lg.shape[-1]).double(), lab_b.view(-1), ignore_index=-100).item())
+                print(variant, mode, "loss %.6f  %.1fs" % (rec[f"{variant}.{mode}.loss"], time.time() - t0), flush=True)
+            ref, low = logits["fp32"], logits["autocast"]
+            idx = sample_idx(ref.shape, 8192, 4321)
+            rec[f"{variant}.logit_idx"] = idx.astype(np.int64)
+            rec[f"{variant}.logit_val"] = ref.reshape(-1)[idx].numpy().astype(np.float32)
+            rec[f"{variant}.autocast_logit_val"] = low.reshape(-1)[idx].numpy().astype(np.float32)
+            rec[f"{variant}.autocast_max_abs"] = np.float32((low - ref).abs().max().item())
+            rec[f"{variant}.autocast_rel_l2"] = np.float32(((low - ref).norm() / ref.norm()).item())
+            names, norms, rels, coss, samp_i, samp_v = [], [], [], [], [], []
+            for n, g32 in grads["fp32"].items():
+                ga = grads["autocast"][n].float()
+                names.append(n)
+                norms.append(g32.double().norm().item())
+                rels.append(((ga - g32).norm() / g32.norm()).item() if g32.norm() > 0 else 0.0)
+                coss.append(F.cosine_similarity(ga.flatten(), g32.flatten(), dim=0).item() if g32.norm() > 0 else 1.0)
+                ii = sample_idx(g32.shape, 256, zlib_seed(n))
+                samp_i.append(ii.astype(np.int64))
+                samp_v.append(g32.reshape(-1)[ii].numpy().astype(np.float32))
+            rec[f"{variant}.grad_names"] = np.array(names)
+            rec[f"{variant}.grad_norm"] = np.array(norms, dtype=np.float64)
+            rec[f"{variant}.grad_rel_l2"] = np.array(rels, dtype=np.float32)
+            rec[f"{variant}.grad_cos"] = np.array(coss, dtype=np.float32)
+            rec[f"{variant}.grad_sample_idx"] = np.stack(samp_i)
+            rec[f"{variant}.grad_sample_val"] = np.stack(samp_v)
+            w = int(np.argmax(rels))
+            print(variant, "autocast gradient at B=16x1024: worst rel-L2 %.3e (%s), worst cos %.5f, median rel-L2 %.3e; "
+                  "logits max|d| %.3e rel-L2 %.3e" % (rels[w], names[w], min(coss), float(np.median(rels)),
+                                                        rec[f"{variant}.autocast_max_abs"], rec[f"{variant}.autocast_rel_l2"]),
+                  flush=True)
+        np.savez_compressed(os.path.join(HERE, "bench_shape.npz"), **rec)
+        print("wrote bench_shape.npz")
         return
     if args.v1_decode:
         import contextlib, io

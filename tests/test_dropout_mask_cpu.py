@@ -58,3 +58,27 @@ def test_step_salt_gives_independent_masks_per_step():
     ka, _ = dr.attn_keep_mask(1, 2, 128, 128, 0.1, 365, 4, step=5)
     kb, _ = dr.attn_keep_mask(1, 2, 128, 128, 0.1, 365, 4, step=6)
     assert abs(ka.mean() - (1 - 26 / 256)) < 1e-2 and (ka != kb).mean() > 0.12
+
+
+@pytest.mark.parametrize("seed,stream", [(365, 1), (1234, 7), (0xDEADBEEFCAFE, 17)])
+def test_attention_mask_keep_rate_and_correlations(seed, stream):
+    """The attention-probability mask (one mix per query row and four consecutive keys, a byte per element): keep rate
+    1 - 26/256, no correlation along a query row (lags inside and across the four-key groups), down a key column,
+    between heads or between batch rows; keep counts per row and per column binomial."""
+    keep, scale = dr.attn_keep_mask(2, 6, 512, 512, 0.1, seed, stream)
+    assert abs(scale - 256.0 / 230.0) < 1e-9
+    k = keep.astype(np.float64)
+    rate = k.mean()
+    assert abs(rate - (1.0 - 26.0 / 256.0)) < 1.5e-3                          # 3.1M samples: sigma = 1.7e-4
+    kf = k - rate
+    var = kf.var()
+    for lag in (1, 2, 3, 4, 5, 8, 16):
+        assert abs((kf[..., :, lag:] * kf[..., :, :-lag]).mean() / var) < 3e-3   # along a query row
+    for lag in (1, 2, 3, 4, 8, 16):
+        assert abs((kf[..., lag:, :] * kf[..., :-lag, :]).mean() / var) < 3e-3   # down a key column
+    assert abs((kf[:, 1:] * kf[:, :-1]).mean() / var) < 3e-3                     # neighbouring heads
+    assert abs((kf[1:] * kf[:-1]).mean() / var) < 3e-3                           # neighbouring batch rows
+    assert 0.9 < k.sum(-1).var() / (512 * rate * (1 - rate)) < 1.1
+    assert 0.9 < k.sum(-2).var() / (512 * rate * (1 - rate)) < 1.1
+    other, _ = dr.attn_keep_mask(2, 6, 512, 512, 0.1, seed, stream + 1)         # another attention site of the step
+    assert abs((kf * (other - other.mean())).mean() / var) < 3e-3 and (keep != other).mean() > 0.15

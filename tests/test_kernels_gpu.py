@@ -464,6 +464,45 @@ def test_attn_dropout_mask_equals_the_restatement(dev, B, H, Lq, causal):
     assert abs(dv_got2 - dv_want2).max() < 2e-2 * max(1.0, dv_want2.max())
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_attn_dropout_mask_element_by_element_in_every_backward_product(dev, causal):
+    """32 queries x 32 keys with K[k] = e_k, Q[q] = e_(32+q), V[k] = e_k and dO = 1: the scores are all zero (uniform
+    P), dP[q, k] = 1, so dS[q, k] = P (keep[q, k] * scale - delta_q) takes two values per row and
+      dQ[q, k]      = dS[q, k]   (the dQ kernel's mask, query on the lane),
+      dK[k, 32 + q] = dS[q, k]   (the dK/dV kernel's mask on dP, key on the lane, words shared through DPP),
+      dV[k, k']     = sum_q Pd[q, k] for k' = k... and O[q, k] = Pd[q, k] (forward),
+    every one of which must show exactly the kept set of oracle/dropout_ref.attn_keep_mask."""
+    from mrmt3 import lib
+    from oracle import dropout_ref as dr
+    B, H, L, p, seed, stream = 3, 2, 32, 0.1, 2 ** 33 + 5, 11
+    eye = torch.eye(64, device=dev)
+    k = eye[:32].repeat(B, H).bfloat16()                   # [B*32, H*64]: K[k] = e_k
+    q = eye[32:].repeat(B, H).bfloat16()                   # Q[q] = e_(32+q): orthogonal to every key
+    v = k.clone()
+    o, lse = lib.attn_fwd(q, k, v, B, H, L, L, causal, p=p, seed=seed, stream_id=stream)
+    keep, scale = dr.attn_keep_mask(B, H, L, L, p, seed, stream)
+    qi, ki = np.arange(L).reshape(L, 1), np.arange(L).reshape(1, L)
+    visible = (ki <= qi) if causal else np.ones((L, L), bool)
+    kept = keep & visible
+    n_vis = visible.sum(1, keepdims=True).astype(np.float64)
+    pd = kept * (scale / n_vis)                                               # dropped, rescaled probabilities
+    got_o = o.float().view(B, L, H, 64).permute(0, 2, 1, 3).cpu().numpy()[..., :32]
+    assert ((got_o != 0) == kept).all()
+    d_o = torch.ones_like(o)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, L, causal, p=p, seed=seed, stream_id=stream)
+    delta = pd.sum(-1, keepdims=True)                                         # rowsum(dO * O) = sum_k Pd[q, k]
+    ds_n = visible * (keep * scale - delta)                                   # n_vis * dS[q, k]: O(1) in every row
+    got_dq = dq.float().view(B, L, H, 64).permute(0, 2, 1, 3).cpu().numpy()[..., :32]          # [B, H, q, k]
+    got_dk = dk.float().view(B, L, H, 64).permute(0, 2, 1, 3).cpu().numpy()[..., 32:]          # [B, H, k, q]
+    err_q = np.abs(got_dq * n_vis - ds_n).max()
+    err_k = np.abs(got_dk.transpose(0, 1, 3, 2) * n_vis - ds_n).max()
+    # kept and dropped elements of a row differ by `scale` = 1.11: a single wrong mask bit is 50x the tolerance
+    assert err_q < 2e-2 and err_k < 2e-2, (err_q, err_k)
+    got_dv = dv.float().view(B, L, H, 64).permute(0, 2, 1, 3).cpu().numpy()   # dV[k, d] = sum_q Pd[q, k] dO[q, d]
+    assert np.abs(got_dv[..., 0] - pd.sum(2)).max() < 2e-2 * pd.sum(2).max()
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 6, 256, 256, False), (1, 6, 128, 128, True), (1, 6, 100, 320, False)])
 def test_attn_f32(dev, B, H, Lq, Lk, causal):
     from mrmt3 import lib

@@ -191,3 +191,34 @@ def test_bucketed_step_with_grouped_weight_gradients_captures_and_equals_eager(d
         assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])
     finally:
         dist.destroy_process_group()
+
+
+def test_failed_capture_falls_back_to_a_correct_eager_step(dev):
+    """a capture that fails half-way (here: no page-locked plan table was left for the grouped weight-gradient
+    launch, the failure DESIGN §6 records) leaves deferred launches behind that name tensors of work that never ran.
+    The eager fallback must not flush them into the gradients: its weights equal those of a trainer that never tried
+    to capture, bit for bit."""
+    import warnings
+    from mrmt3.trainer import Trainer
+    data = _batches(dev, 2, B=8, L=256)                      # 2048 decoder rows: the grouped launch takes these shapes
+    runs = {}
+    for sabotage in (False, True):
+        m = _model("t5", dev, dropout_rate=0.0)
+        tr = Trainer(m, lr=1e-3, graph=sabotage)
+        for i in range(4):
+            a, t, _ = data[i % 2]
+            if sabotage and i == 2:                           # the step that captures: take its spare tables away
+                assert m.engine.tn_group is not None and len(m.engine.tn_group._spare) > 0
+                m.engine.tn_group._spare.clear()
+                with warnings.catch_warnings(record=True) as w:
+                    warnings.simplefilter("always")
+                    tr.train_step(a, t, audio=True)
+                assert any("capture of the training step failed" in str(x.message) for x in w)
+                assert not tr.use_graph and not tr.graph_captured
+            else:
+                tr.train_step(a, t, audio=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(m.flat.P).all()
+        runs[sabotage] = (m.flat.P.clone(), m.flat.M.clone(), m.flat.V.clone())
+    for a, b in zip(runs[False], runs[True]):
+        assert torch.equal(a, b)
