@@ -158,6 +158,32 @@ def cpu_baseline(seconds):
     torch.set_num_threads(cores)
     # ... and at N = every core of the host, in a child process with a deadline: torch's intra-op pool collapses far
     # below this host's core count on T5-small sized matmuls (round 1: 256 threads took 296 s per step)
+    def child_fwd_bwd(threads, deadline):
+        """fwd + CE + bwd of one segment at `threads` intra-op threads, in a child process with a deadline."""
+        code = ("import sys,time,torch;sys.path[:0]=[%r,%r];from mrmt3.synthetic import T5_SMALL,golden_weights,synth_mel,synth_labels;"
+                "from oracle import t5_ref;torch.set_num_threads(%d);sd={k:torch.from_numpy(v).requires_grad_(True) for k,v in golden_weights(T5_SMALL).items()};"
+                "mel=torch.from_numpy(synth_mel(1));lab=torch.from_numpy(synth_labels(1));f=lambda:t5_ref.ce_loss(t5_ref.forward_logits(sd,T5_SMALL,mel,lab),lab).backward();"
+                "f();ts=[]\nfor _ in range(3):\n t=time.perf_counter();f();ts.append(time.perf_counter()-t)\nprint(min(ts))") % (
+                    os.path.join(ROOT, "mr-mt3_amd"), ROOT, threads)
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=deadline)
+            return {"threads": threads, "segments_per_s": 1.0 / float(r.stdout.strip().splitlines()[-1])}
+        except Exception as e:
+            return {"threads": threads, "segments_per_s": None, "note": "no result within %d s (%s)" % (deadline, type(e).__name__)}
+    # one thread per PHYSICAL core (BASELINE.md §2 "all physical cores"): distinct (package, core) pairs of /proc/cpuinfo
+    try:
+        pairs, pkg = set(), None
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("physical id"):
+                pkg = l.split(":")[1].strip()
+            elif l.startswith("core id"):
+                pairs.add((pkg, l.split(":")[1].strip()))
+        phys = len(pairs) or None
+    except Exception:
+        phys = None
+    if phys and phys != cores:
+        stages["fwd_bwd_b1_one_thread_per_physical_core"] = child_fwd_bwd(phys, 60)
     ncpu = os.cpu_count() or cores
     if ncpu > cores:
         code = ("import sys,time,torch;sys.path[:0]=[%r,%r];from mrmt3.synthetic import T5_SMALL,golden_weights,synth_mel,synth_labels;"
@@ -201,10 +227,14 @@ def inference_rtf(dev, tokens, batch):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         assert ids.shape == (nb, tokens + 1)
-        # bytes one decode step has to move: 45.6 MB of bf16 decoder weights + lm_head (once per step for
-        # every group of 16 sequences above 8, once per sequence below) + this step's K/V: the self-attention cache
-        # (mean length tokens/2) and the projected encoder states (256 frames), 8 layers x 2 x 384 x 2 B per position
-        w_bytes = 45.6e6 * (nb if nb <= 8 else -(-nb // 16))
+        # bytes one decode step has to move: 45.6 MB of bf16 decoder weights + lm_head + this step's K/V:
+        # the self-attention cache (mean length tokens/2) and the projected encoder states (256 frames), 8 layers x
+        # 2 x 384 x 2 B per position
+        # ALGORITHMIC bytes of a step: the weights once + this step's K/V.  What the kernels actually stream is more —
+        # they re-read the weights once per sequence (<= 8 sequences) or per group of 16 — and is reported next to it
+        # as wasted traffic, not counted as achieved bandwidth.
+        w_bytes = 45.6e6
+        rereads = nb if nb <= 8 else -(-nb // 16)
         kv_bytes = nb * 8 * 2 * 384 * 2 * (tokens / 2 + 256)
         step_s = dt / tokens
         out[name] = dict(segments=nb, tokens=tokens, seconds=dt, rtf=dt / (nb * SEG_SECONDS),
@@ -212,6 +242,8 @@ def inference_rtf(dev, tokens, batch):
                          roofline_decode={"bound": "hbm", "bytes_per_step": w_bytes + kv_bytes,
                                           "achieved": (w_bytes + kv_bytes) / step_s / 1e9, "peak": PEAK_HBM_GBS,
                                           "unit": "GB/s", "frac": (w_bytes + kv_bytes) / step_s / 1e9 / PEAK_HBM_GBS,
+                                          "weight_rereads_per_step": rereads,
+                                          "streamed_bytes_per_step": w_bytes * rereads + kv_bytes,
                                           "launch_chain_floor_ms": 66 * 1.77e-3})
     # MR-MT3 proper (segment memory from the previous segment's tokens): a recording is a sequential chain,
     # several recordings decode in lockstep, one batch row each
@@ -362,8 +394,23 @@ def main():
                                    "themselves are graph replays: events cannot be placed inside); the 16 wi projections "
                                    "(GEMM + gated-GELU epilogue in one launch) are their own family gemm_nt_geglu_bf16, "
                                    "priced at the GEMM's FLOPs; gemm_tn_bf16 = the grouped weight-gradient launch + its reduce",
-                           "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam.items()},
+                           "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam.items() if "@" not in k},
+                           # attn_*: priced at the FULL score square, as the reference computes it;
+                           # attn_*@executed: the FLOPs the kernels issue (causal key tiles above the diagonal skipped)
                            "families_achieved": {k: rate(v) for k, v in fam.items()}}
+        # HBM side of the whole step: bytes per step from the committed whole-step PMC table (profiles/tools/
+        # pmc_step_traffic.sh) over this run's step time, next to the MFMA fraction (the step holds 14.4 TFLOP)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json")) as fh:
+                st = json.load(fh)
+            step_s = dt / args.steps
+            res["roofline"]["step"] = {"step_bytes": st["step_bytes"], "hbm_GBps": st["step_bytes"] / step_s / 1e9,
+                                       "hbm_frac": st["step_bytes"] / step_s / 1e9 / PEAK_HBM_GBS,
+                                       "mfma_TFLOPs": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12,
+                                       "mfma_frac": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12 / PEAK_BF16_TFLOPS,
+                                       "source": "profiles/r03_pmc_step_traffic.json (B = 64 table; valid for --batch 64)"}
+        except Exception:
+            pass
     sync()
     if rank == 0 and not args.no_inference:
         del trainer, model

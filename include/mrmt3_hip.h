@@ -104,6 +104,11 @@ int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int l
 size_t mrmt3_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1,
                   int N2, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The same product in exact f32 (plain FMAs in row order, one writer per element, no workspace): the weight gradients
+ * of the fp32 training / parity path — the reference trains at `precision: 32`
+ * (config/config_slakh_segmem.yaml:47); torch autograd's `grad_output.t().mm(input)` of nn.Linear. */
+int mrmt3_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                      int accumulate, void* stream);
 /* Deferred form for the 45-50 weight gradients of a training step: mrmt3_gemm_tn_partial only leaves the
  * mrmt3_gemm_tn_splits(M,N1,N2) f32 slabs [split][N1][N2] in `slabs` (>= mrmt3_gemm_tn_workspace_bytes, one buffer per
  * site, kept until reduced); mrmt3_tn_reduce_sites then sums the slabs of n_sites sites into their C in ONE launch
@@ -186,23 +191,30 @@ int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int 
  * bf16(O - bf16(O)), the low half of the f32 output: hand it to mrmt3_attn_bwd and delta = rowsum(dO*O) is formed from
  * O to ~16 bits, which keeps dS = P*(dP - delta) accurate when the value rows share a large common component.
  * causal!=0 masks key > query.  Attention-probability
- * dropout (p_drop) uses a counter hash of (seed, b, h, q, k).  dtype = MRMT3_BF16 (MFMA flash
- * kernel) or MRMT3_F32 (exact-f32 reference-grade kernel used for parity/decoding). */
+ * dropout (p_drop) uses a counter hash of (seed, b, h, q, k >> 2), a byte per key.  dtype = MRMT3_BF16 (MFMA flash
+ * kernel) or MRMT3_F32 (exact-f32 kernel: fp32 training, parity, decoding prefill; same masks). */
 int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
                    int ldo, void* o_lo, float* lse, int B, int H, int Lq, int Lk, int causal, int dtype,
                    float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
-/* backward (bf16 only): delta [B][H][Lq] f32 scratch is written by the call.
+/* backward of the bf16 kernel: delta [B][H][Lq] f32 scratch is written by the call.
  * dq/dk/dv share the layout (and strides) of q/k/v. */
 int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                    const void* o, int ldo, const void* o_lo, const void* d_o, int lddo, const float* lse, float* delta,
                    void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Lq,
                    int Lk, int causal, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
+/* backward of the exact-f32 kernel (autograd of HF T5Attention at `precision: 32`): everything f32, the same masks as
+ * the f32 forward; one workgroup per query row (delta, dQ) and per key row (dK, dV), fixed summation order. */
+int mrmt3_attn_bwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                       int ldo, const float* d_o, int lddo, const float* lse, float* delta, float* dq, int lddq,
+                       float* dk, int lddk, float* dv, int lddv, int B, int H, int Lq, int Lk, int causal,
+                       float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 
 /* ---- K7: gated-GELU (HF T5DenseGatedGeluDense: gelu_new(h0) * h1, then dropout) ----------------
  * h [rows][2*dff] = [wi_0 x | wi_1 x] -> g [rows][dff] */
 int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop,
                     uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
-int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
+/* h, dg, dh all of `dtype` (bf16 or f32) */
+int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, int dtype, float p_drop,
                     uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 
 /* K2 + K7 in one launch (the feed-forward input projection, models/t5.py T5DenseGatedGeluDense.forward):
@@ -235,9 +247,9 @@ int mrmt3_embed_bwd(const int64_t* ids, const float* dx, float* dtable, int rows
 int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos, float* x, int rows, int seq_len,
                      int d, int pos_offset, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id,
                      void* stream);
-/* out_bf16 = dropmask(dx)  (gradient w.r.t. the GEMM output feeding addpos / any dropout site) */
-int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed, const int32_t* step_dev,
-                        uint32_t stream_id, void* stream);
+/* out (bf16 or f32) = dropmask(dx)  (gradient w.r.t. the GEMM output feeding addpos / any dropout site) */
+int mrmt3_dropmask_cast(const float* dx, void* out, int out_dtype, size_t n, float p_drop, uint64_t seed,
+                        const int32_t* step_dev, uint32_t stream_id, void* stream);
 
 /* ---- K9: cross-entropy over lm_head logits (tasks/mt3_net.py:32-35; weighted variant :96-108) ---
  * logits [rows][V] f32, targets [rows] int64 (ignore_index -100).  Per row (w_i, n_i) = (1,1) for a

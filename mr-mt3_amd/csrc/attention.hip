@@ -23,153 +23,8 @@
 // The f32 kernel is a plain exact-f32 implementation used for the fp32 parity / greedy-decode path.
 #include "common.h"
 
-#define HD 64          // head dim (d_kv)
+#include "attn_common.h"
 
-__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-}
-__device__ __forceinline__ bf16x8 cat8(s16x4 lo, s16x4 hi) {
-  return bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-}
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
-  bf16x8 r;
-  r[0] = (short)f2bf(lo[0]); r[1] = (short)f2bf(lo[1]); r[2] = (short)f2bf(lo[2]); r[3] = (short)f2bf(lo[3]);
-  r[4] = (short)f2bf(hi[0]); r[5] = (short)f2bf(hi[1]); r[6] = (short)f2bf(hi[2]); r[7] = (short)f2bf(hi[3]);
-  return r;
-}
-
-// attention-probability dropout.  Element (q,k) of head-matrix bh takes byte (k & 3) of the 32-bit word
-// W(bh, q, k >> 2) = mix24(seed + bh*CB + q*CQ + (k >> 2)*CK): one mix per query row and group of four consecutive keys.
-// Forward and dQ hold exactly such a group per lane and accumulator tile (query on the lane, keys 4g..4g+3 in the four
-// registers): ONE mix per 4 elements, the lane's part of the argument is loop-invariant and the key tile's part a scalar.
-// dK/dV hold the transposed group (key on the lane, four consecutive queries): the four lanes of a quad hold the same
-// four queries for keys 4g..4g+3, so each computes the word of ONE query and reads the other three through DPP
-// quad-permutes (a v_and with the lane's byte mask as the DPP instruction, then a compare with the threshold shifted into
-// that byte).  Round 2 used 2x2 groups — two mixes per 4 elements in every layout — and the mask was 42-53 % of the
-// kernels' vector instructions (profiles/r03_attn_isa_mix.txt).  The drop probability is quantised to thresh8/256
-// (p=0.1 -> 26/256) and the keep scale is 256/(256-thresh8), so forward and backward stay exactly consistent and
-// unbiased.  The kernels only ZERO the dropped probabilities in the loop; the constant keep scale is applied once to
-// the accumulated O / dV (and inside the fused multiply-add that forms dS).  oracle/dropout_ref.attn_keep_mask restates
-// the generator; tests compare the kernels' kept sets with it bit for bit and check its statistics on the CPU.
-struct AttnDrop {
-  const int* step;   // nullable device step counter (see DropCfg::step)
-  unsigned seed;
-  unsigned thresh8;  // 0 = off
-  float scale;
-};
-#define DROP_CQ 0x9E3779B1u
-#define DROP_CK 0x85EBCA6Bu
-#define DROP_CB 0xC2B2AE35u
-__host__ inline AttnDrop make_attn_drop(float p, unsigned long long seed, unsigned stream, const int* step) {
-  AttnDrop d;
-  d.step = p > 0.f ? step : nullptr;
-  d.seed = ((unsigned)seed ^ (unsigned)(seed >> 32)) + stream * 0x27D4EB2Fu;
-  if (p <= 0.f) { d.thresh8 = 0; d.scale = 1.f; }
-  else {
-    d.thresh8 = (unsigned)(p * 256.0f + 0.5f);
-    if (d.thresh8 > 255) d.thresh8 = 255;
-    d.scale = 256.0f / (256.0f - (float)d.thresh8);
-  }
-  return d;
-}
-// VALU and MFMA do not overlap on a gfx950 SIMD (profiles/tools/coissue_probe.hip), so every instruction of
-// the mask costs kernel time.  32-bit integer multiplies are quarter rate; v_mul_u32_u24 is full rate, and
-// with the xor-shifts folding the high bits down first the two 24-bit multiplies mix just as well here
-// (byte histograms, keep rate and neighbour correlations checked against the 32-bit finaliser).
-__device__ __forceinline__ unsigned mix24(unsigned x) {
-  x ^= x >> 16; x = __umul24(x, 0x7feb35u); x ^= x >> 15; x = __umul24(x, 0x6ca68bu);
-  return x;
-}
-// byte `byte` (0..3, a compile-time constant: an SDWA byte select on the compare) of the group's word decides element `byte`
-__device__ __forceinline__ float drop_sel(const AttnDrop& d, unsigned g, int byte, float v) {
-  return ((g >> (8 * byte)) & 0xFFu) >= d.thresh8 ? v : 0.f;
-}
-// dK/dV layout: word of query r of the lane's quad, fetched from the lane that computed it (quad_perm [r,r,r,r])
-template <int R>
-__device__ __forceinline__ unsigned quad_word(unsigned w) {
-  return (unsigned)__builtin_amdgcn_mov_dpp((int)w, R * 0x55, 0xF, 0xF, true);
-}
-// max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): gfx950's v_permlane16/32_swap are
-// plain VALU moves, so the reduction has no LDS (ds_bpermute) round trip in the softmax's dependency chain
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float rows_max(float v) {
-  unsigned u = __float_as_uint(v);
-  u32x2_t r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  u = __float_as_uint(fmaxf(__uint_as_float(r.x), __uint_as_float(r.y)));
-  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
-}
-#define LOG2E 1.4426950408889634f
-#define LN2 0.6931471805599453f
-
-struct AttnParams {
-  const bf16_t *q, *k, *v, *o, *d_o;
-  // low half of the f32 attention output, bf16(O - bf16(O)): written by the forward next to `out` when the caller
-  // keeps the tape, read back by the dQ kernel so that delta = rowsum(dO * O) sees O to ~16 bits.  With delta taken
-  // from the bf16-rounded O alone, dP - delta loses the exact cancellation of whatever the value rows have in common
-  // (dS_ij = P_ij dO_i.(V_j - O_i)): q/k weight gradients were 3x further from the fp32 gradient than the
-  // reference's own bf16-autocast run (tests/golden/bf16_bound.npz), the v/o gradients were not.
-  const bf16_t* o_lo_in;
-  bf16_t* o_lo_out;
-  bf16_t *out, *dq, *dk, *dv;
-  float* lse;
-  float* delta;
-  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
-  int B, H, Lq, Lk, causal;
-  AttnDrop drop;
-};
-
-// ---- LDS tiles: [rows][64] bf16 = 128-B rows, the 16-B chunk index XOR-ed with (row & 7).  Tiles are
-// filled by buffer_load ... lds (memory -> LDS, no VGPR round trip, see blds_rows8 below): one wave-instruction
-// covers 8 rows x 128 B linearly, so the swizzle is applied to each lane's SOURCE chunk.  The same image
-// serves ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads, both conflict-free.
-// Rows past the end of the tensor are zero-filled by the buffer bounds check (their scores are masked).
-__device__ __forceinline__ bf16x8 lds_row8(const unsigned char* tile, int row, int c) {
-  return *(const bf16x8*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
-}
-// transposed fragment: rows {row..row+3 via the lane's fq} and +16, chunk c, 8-byte half `sub`
-__device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* tile, int row, int c, int sub) {
-  const unsigned char* a = tile + row * 128 + ((c ^ (row & 7)) << 4) + sub;
-  return cat8(lds_tr16(a), lds_tr16(a + 16 * 128));
-}
-
-// Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8) and each XCD has its own L2.  All tiles
-// of one (batch, head) stream the same K/V (or Q/dO) rows, so they are made to run on ONE XCD, back to back:
-// XCD x takes the contiguous range [x*n/8, (x+1)*n/8) of the (b, h, tile) space, tile fastest.  Without this the
-// 8 query tiles of a head land on 8 different XCDs and every one of them pulls K/V through the fabric again.
-__device__ __forceinline__ void attn_tile(int& tile, int& h, int& b) {
-  const int nt = gridDim.x, H = gridDim.y;
-  const int n = nt * H * (int)gridDim.z;
-  int w = blockIdx.x + nt * (blockIdx.y + H * blockIdx.z);
-  if ((n & 7) == 0) w = (w & 7) * (n >> 3) + (w >> 3);
-  tile = w % nt;
-  const int bh = w / nt;
-  h = bh % H;
-  b = bh / H;
-}
-// causal launches pair the 128-row tiles (see the kernels): ceil(n/2) workgroups along x
-static inline int attn_grid_x(int L, int causal) {
-  const int n = ceil_div(L, 128);
-  return causal ? (n + 1) / 2 : n;
-}
-// K/V (Q/dO) tiles are staged with buffer_load ... lds: the per-lane byte offset inside an 8-row group is constant
-// for the whole kernel, the tile offset is a scalar, and rows past the end of the tensor (or a whole tile that is
-// switched off by an out-of-range scalar offset) come back as zeros without touching memory — so the loop needs no
-// address arithmetic, no row clamp and no branch around the prefetch.
-#define BUF_OOB 0x7FFF0000
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const bf16_t* base, int nrows, int ld) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, ((nrows - 1) * ld + HD) * 2, 0x00020000);
-}
-__device__ __forceinline__ unsigned rows8_lane_off(int ld, int lane) {     // row lane>>3, swizzled 16-B chunk
-  return (unsigned)(((lane >> 3) * ld + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
-}
-__device__ __forceinline__ void blds_rows8(__amdgpu_buffer_rsrc_t r, unsigned lane_off, int tile_byte_off, unsigned char* dst) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, lane_off, tile_byte_off, 0, 0);
-}
-#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -697,10 +552,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
 // ------------------------------------------------------------------------------------------------
 // exact-f32 attention (parity path): one workgroup per (query, head, batch)
 // ------------------------------------------------------------------------------------------------
+// element (q, key) of head-matrix bh kept?  (the generator of the bf16 kernels, one element at a time)
+__device__ __forceinline__ bool attn_keep1(const AttnDrop& d, unsigned drop_bh, int q, int key) {
+  const unsigned w = mix24(drop_bh + (unsigned)q * DROP_CQ + ((unsigned)key >> 2) * DROP_CK);
+  return ((w >> (8 * (key & 3))) & 0xFFu) >= d.thresh8;
+}
+
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                        int ldk, const float* __restrict__ v, int ldv,
                                                        float* __restrict__ o, int ldo, float* __restrict__ lse, int H,
-                                                       int Lq, int Lk, int causal) {
+                                                       int Lq, int Lk, int causal, AttnDrop drop) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[Lk] | q[64] | red[8] | part[4][64]
   float* sc = sm;
   float* qs = sm + Lk;
@@ -740,15 +601,157 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   if (lane == 0) red[4 + wave] = se;
   __syncthreads();
   se = red[4] + red[5] + red[6] + red[7];
+  if (drop.thresh8) {      // the normaliser is the sum of ALL probabilities; dropped ones leave the product only
+    const unsigned drop_bh = drop.seed + step_salt(drop.step) + (unsigned)(b * H + h) * DROP_CB;
+    for (int key = tid; key < nk; key += 256)
+      if (!attn_keep1(drop, drop_bh, qi, key)) sc[key] = 0.f;
+    __syncthreads();
+  }
   float acc = 0.f;
   for (int key = wave; key < nk; key += 4) acc = fmaf(sc[key], vb[(size_t)key * ldv + lane], acc);
   part[wave * 64 + lane] = acc;
   __syncthreads();
   if (tid < 64) {
     const float r = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-    o[((size_t)b * Lq + qi) * ldo + h * HD + tid] = r / se;
+    o[((size_t)b * Lq + qi) * ldo + h * HD + tid] = r * drop.scale / se;
   }
   if (tid == 0 && lse) lse[((size_t)b * H + h) * Lq + qi] = mx + logf(se);
+}
+
+// exact-f32 backward of the same (the reference trains in fp32, config/config_slakh_segmem.yaml:47 `precision: 32`):
+// (1) one workgroup per query row: delta = rowsum(dO * O), dS = P (keep * scale * dP - delta), dQ = dS . K;
+// (2) one workgroup per key row: dV = Pd^T dO, dK = dS^T Q.  Every sum runs in a fixed order (no atomics).
+__global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                              int ldk, const float* __restrict__ v, int ldv,
+                                                              const float* __restrict__ o, int ldo,
+                                                              const float* __restrict__ d_o, int lddo,
+                                                              const float* __restrict__ lse, float* __restrict__ delta,
+                                                              float* __restrict__ dq, int lddq, int H, int Lq, int Lk,
+                                                              int causal, AttnDrop drop) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // ds[Lk] | q[64] | dO[64] | red[4] | part[4][64]
+  float* sc = sm;
+  float* qs = sm + Lk;
+  float* dos = qs + 64;
+  float* red = dos + 64;
+  float* part = red + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const size_t qrow = (size_t)b * Lq + qi;
+  const float* kb = k + (size_t)b * Lk * ldk + h * HD;
+  const float* vb = v + (size_t)b * Lk * ldv + h * HD;
+  const unsigned drop_bh = drop.seed + step_salt(drop.step) + (unsigned)(b * H + h) * DROP_CB;
+  if (tid < 64) {
+    qs[tid] = q[qrow * ldq + h * HD + tid];
+    dos[tid] = d_o[qrow * lddo + h * HD + tid];
+  }
+  __syncthreads();
+  float dl = 0.f;
+  if (wave == 0) {
+    dl = wave_sum(dos[lane] * o[qrow * ldo + h * HD + lane]);
+    if (lane == 0) { red[0] = dl; delta[((size_t)b * H + h) * Lq + qi] = dl; }
+  }
+  __syncthreads();
+  dl = red[0];
+  const float l = lse[((size_t)b * H + h) * Lq + qi];
+  const int nk = causal ? min(Lk, qi + 1) : Lk;
+  for (int key = tid; key < nk; key += 256) {
+    const float* kr = kb + (size_t)key * ldk;
+    const float* vr = vb + (size_t)key * ldv;
+    float sv = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const f32x4 kv = *(const f32x4*)(kr + d), vv = *(const f32x4*)(vr + d);
+      sv = fmaf(qs[d], kv.x, sv); sv = fmaf(qs[d + 1], kv.y, sv); sv = fmaf(qs[d + 2], kv.z, sv); sv = fmaf(qs[d + 3], kv.w, sv);
+      dp = fmaf(dos[d], vv.x, dp); dp = fmaf(dos[d + 1], vv.y, dp); dp = fmaf(dos[d + 2], vv.z, dp); dp = fmaf(dos[d + 3], vv.w, dp);
+    }
+    const float pr = expf(sv - l);
+    if (drop.thresh8) dp = attn_keep1(drop, drop_bh, qi, key) ? dp * drop.scale : 0.f;
+    sc[key] = pr * (dp - dl);
+  }
+  __syncthreads();
+  float acc = 0.f;
+  for (int key = wave; key < nk; key += 4) acc = fmaf(sc[key], kb[(size_t)key * ldk + lane], acc);
+  part[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (tid < 64) dq[qrow * lddq + h * HD + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+}
+
+__global__ __launch_bounds__(256) void attn_f32_bwd_dkdv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                                int ldk, const float* __restrict__ v, int ldv,
+                                                                const float* __restrict__ d_o, int lddo,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dk, int lddk, float* __restrict__ dv,
+                                                                int lddv, int H, int Lq, int Lk, int causal, AttnDrop drop) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // pd[Lq] | ds[Lq] | k[64] | v[64] | part[2][4][64]
+  float* pd = sm;
+  float* ds = sm + Lq;
+  float* ks = ds + Lq;
+  float* vs = ks + 64;
+  float* part = vs + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int key = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const size_t krow = (size_t)b * Lk + key;
+  const float* qb = q + (size_t)b * Lq * ldq + h * HD;
+  const float* dob = d_o + (size_t)b * Lq * lddo + h * HD;
+  const float* lseb = lse + ((size_t)b * H + h) * Lq;
+  const float* dltb = delta + ((size_t)b * H + h) * Lq;
+  const unsigned drop_bh = drop.seed + step_salt(drop.step) + (unsigned)(b * H + h) * DROP_CB;
+  if (tid < 64) {
+    ks[tid] = k[krow * ldk + h * HD + tid];
+    vs[tid] = v[krow * ldv + h * HD + tid];
+  }
+  __syncthreads();
+  const int q_lo = causal ? key : 0;
+  for (int qi = q_lo + tid; qi < Lq; qi += 256) {
+    const float* qr = qb + (size_t)qi * ldq;
+    const float* dr = dob + (size_t)qi * lddo;
+    float sv = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const f32x4 qv = *(const f32x4*)(qr + d), dv4 = *(const f32x4*)(dr + d);
+      sv = fmaf(qv.x, ks[d], sv); sv = fmaf(qv.y, ks[d + 1], sv); sv = fmaf(qv.z, ks[d + 2], sv); sv = fmaf(qv.w, ks[d + 3], sv);
+      dp = fmaf(dv4.x, vs[d], dp); dp = fmaf(dv4.y, vs[d + 1], dp); dp = fmaf(dv4.z, vs[d + 2], dp); dp = fmaf(dv4.w, vs[d + 3], dp);
+    }
+    float pr = expf(sv - lseb[qi]);
+    float keep = 1.f;
+    if (drop.thresh8) keep = attn_keep1(drop, drop_bh, qi, key) ? drop.scale : 0.f;
+    pd[qi] = pr * keep;
+    ds[qi] = pr * (dp * keep - dltb[qi]);
+  }
+  __syncthreads();
+  float av = 0.f, ak = 0.f;
+  for (int qi = q_lo + wave; qi < Lq; qi += 4) {
+    av = fmaf(pd[qi], dob[(size_t)qi * lddo + lane], av);
+    ak = fmaf(ds[qi], qb[(size_t)qi * ldq + lane], ak);
+  }
+  part[wave * 64 + lane] = av;
+  part[256 + wave * 64 + lane] = ak;
+  __syncthreads();
+  if (tid < 64) {
+    dv[krow * lddv + h * HD + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    dk[krow * lddk + h * HD + tid] = (part[256 + tid] + part[320 + tid]) + (part[384 + tid] + part[448 + tid]);
+  }
+}
+
+extern "C" int mrmt3_attn_bwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                  int ldo, const float* d_o, int lddo, const float* lse, float* delta, float* dq, int lddq,
+                                  float* dk, int lddk, float* dv, int lddv, int B, int H, int Lq, int Lk, int causal,
+                                  float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_bwd_f32: null pointer");
+  MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_bwd_f32: bad sizes");
+  MR_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && lddo % 4 == 0, "attn_bwd_f32: strides must be multiples of 4");
+  const size_t shm_q = (size_t)(Lk + 64 + 64 + 4 + 256) * sizeof(float), shm_k = (size_t)(2 * Lq + 128 + 512) * sizeof(float);
+  MR_CHECK_ARG(shm_q <= 160 * 1024 && shm_k <= 160 * 1024, "attn_bwd_f32: sequence too long for the parity kernel");
+  const AttnDrop drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_f32_bwd_dq_kernel, dim3(Lq, H, B), dim3(256), shm_q, s, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo,
+                     lse, delta, dq, lddq, H, Lq, Lk, causal, drop);
+  MR_CHECK_LAUNCH("attn_bwd_f32 dq");
+  hipLaunchKernelGGL(attn_f32_bwd_dkdv_kernel, dim3(Lk, H, B), dim3(256), shm_k, s, q, ldq, k, ldk, v, ldv, d_o, lddo, lse,
+                     delta, dk, lddk, dv, lddv, H, Lq, Lk, causal, drop);
+  MR_CHECK_LAUNCH("attn_bwd_f32 dkdv");
+  mrmt3_count(MRMT3_CNT_ATTN_F32);
+  return MRMT3_OK;
 }
 
 extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
@@ -758,12 +761,12 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_fwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MRMT3_F32) {
-    MR_CHECK_ARG(p_drop == 0.f, "attn_fwd: the f32 parity kernel has no dropout");
     MR_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "attn_fwd: f32 strides must be multiples of 4");
     const size_t shm = (size_t)(Lk + 64 + 8 + 256) * sizeof(float);
     MR_CHECK_ARG(shm <= 160 * 1024, "attn_fwd f32: Lk too large");
     hipLaunchKernelGGL(attn_f32_kernel, dim3(Lq, H, B), dim3(256), shm, s, (const float*)q, ldq, (const float*)k, ldk,
-                       (const float*)v, ldv, (float*)o, ldo, lse, H, Lq, Lk, causal);
+                       (const float*)v, ldv, (float*)o, ldo, lse, H, Lq, Lk, causal,
+                       make_attn_drop(p_drop, seed, stream_id, step_dev));
     MR_CHECK_LAUNCH("attn_fwd f32");
     mrmt3_count(MRMT3_CNT_ATTN_F32);
     return MRMT3_OK;

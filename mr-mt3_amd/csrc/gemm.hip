@@ -613,3 +613,67 @@ extern "C" int mrmt3_gemm_tn(const void* A, int lda, const void* B, int ldb, flo
   MR_CHECK_LAUNCH("gemm_tn reduce");
   return MRMT3_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// exact-f32 TN for the fp32 training / parity path (the reference trains at `precision: 32`):
+// C[N1,N2] (+)= A[M,N1]^T . B[M,N2], plain f32 FMAs in row order — one workgroup per 64x64 tile of C, every thread a
+// 4x4 block, 16 token rows staged per step.  No split over M: one writer per element, a fixed summation order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                          int ldb, float* __restrict__ C, int ldc, int M, int N1, int N2,
+                                                          int accumulate) {
+  __shared__ float As[16][64], Bs[16][64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n1_0 = blockIdx.y * 64, n2_0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;      // staging: row lr of 16, 4 consecutive columns
+  for (int m0 = 0; m0 < M; m0 += 16) {
+    const int m = m0 + lr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c1 = n1_0 + lc + e, c2 = n2_0 + lc + e;
+      As[lr][lc + e] = (m < M && c1 < N1) ? A[(size_t)m * lda + c1] : 0.f;
+      Bs[lr][lc + e] = (m < M && c2 < N2) ? B[(size_t)m * ldb + c2] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = n1_0 + ty * 4 + i;
+    if (r >= N1) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = n2_0 + tx * 4 + j;
+      if (c < N2) {
+        float* p = C + (size_t)r * ldc + c;
+        *p = accumulate ? *p + acc[i][j] : acc[i][j];
+      }
+    }
+  }
+}
+
+extern "C" int mrmt3_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                                 int accumulate, void* stream) {
+  MR_CHECK_ARG(A && B && C, "gemm_tn_f32: null pointer");
+  MR_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0 && lda >= N1 && ldb >= N2 && ldc >= N2, "gemm_tn_f32: bad sizes");
+  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((unsigned)ceil_div(N2, 64), (unsigned)ceil_div(N1, 64)), dim3(256), 0,
+                     (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N1, N2, accumulate);
+  MR_CHECK_LAUNCH("gemm_tn_f32");
+  mrmt3_count(MRMT3_CNT_TN_F32);
+  return MRMT3_OK;
+}

@@ -469,7 +469,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
 // Returns 1 if the shape was launched on the second-generation kernel, 0 if the caller should use gemm.hip's.
 int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        int out_dtype, int accumulate, hipStream_t s) {
-  if (M < 4096 || N < 256 || N % 128 != 0 || K % 128 != 0 || K < 128) return 0;      // (an even number of K steps)
+  int min_m = 4096;
+  { const char* e = getenv("MRMT3_GEMM8_MIN_M"); if (e && atoi(e) >= 128) min_m = atoi(e); }      // tuning only
+  if (M < min_m || N < 256 || N % 128 != 0 || K % 128 != 0 || K < 128) return 0;      // (an even number of K steps)
   // Shapes this kernel is measured to win on (profiles/r02_gemm_ab.txt).  Not: a last column tile that is half
   // overlap (N % 256 == 128: qkv 1152, cq 384 — 11-33 % of the MFMAs redone), a tile count that leaves a fractional
   // wave of workgroups (ckv: 384 tiles on 256 CUs), the accumulate form (one launch per decoder layer).

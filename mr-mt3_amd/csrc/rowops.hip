@@ -404,7 +404,8 @@ __global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ g, int
   }
 }
 
-__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ dg, bf16_t* __restrict__ dh,
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dg, T* __restrict__ dh,
                                  int rows, int dff, DropCfg d) {
   DROP_STEP(d);
   const size_t n8 = (size_t)rows * dff / 8;
@@ -413,12 +414,12 @@ __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __r
     const size_t row = i / dff8;
     const int col = (int)(i % dff8) * 8;
     float a[8], b[8], go[8], da[8], db[8];
-    load4<bf16_t>(h + row * 2 * dff + col, a);
-    load4<bf16_t>(h + row * 2 * dff + col + 4, a + 4);
-    load4<bf16_t>(h + row * 2 * dff + dff + col, b);
-    load4<bf16_t>(h + row * 2 * dff + dff + col + 4, b + 4);
-    load4<bf16_t>(dg + row * dff + col, go);
-    load4<bf16_t>(dg + row * dff + col + 4, go + 4);
+    load4<T>(h + row * 2 * dff + col, a);
+    load4<T>(h + row * 2 * dff + col + 4, a + 4);
+    load4<T>(h + row * 2 * dff + dff + col, b);
+    load4<T>(h + row * 2 * dff + dff + col + 4, b + 4);
+    load4<T>(dg + row * dff + col, go);
+    load4<T>(dg + row * dff + col + 4, go + 4);
     if (d.thresh) {
       float m[8];
       drop_mask4(d, 2 * i, m);
@@ -433,10 +434,10 @@ __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __r
       da[e] = go[e] * b[e] * fd;
       db[e] = go[e] * f;
     }
-    store4<bf16_t>(dh + row * 2 * dff + col, da);
-    store4<bf16_t>(dh + row * 2 * dff + col + 4, da + 4);
-    store4<bf16_t>(dh + row * 2 * dff + dff + col, db);
-    store4<bf16_t>(dh + row * 2 * dff + dff + col + 4, db + 4);
+    store4<T>(dh + row * 2 * dff + col, da);
+    store4<T>(dh + row * 2 * dff + col + 4, da + 4);
+    store4<T>(dh + row * 2 * dff + dff + col, db);
+    store4<T>(dh + row * 2 * dff + dff + col + 4, db + 4);
   }
 }
 
@@ -460,12 +461,16 @@ extern "C" int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dt
   return MRMT3_OK;
 }
 
-extern "C" int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, float p_drop,
+extern "C" int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, int dtype, float p_drop,
                                uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(h && dg && dh && rows > 0 && dff % 8 == 0, "geglu_bwd: bad args");
   DropCfg d = make_drop(p_drop, seed, stream_id, step_dev);
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)h, (const bf16_t*)dg, (bf16_t*)dh, rows, dff, d);
+  if (dtype == MRMT3_F32)
+    hipLaunchKernelGGL(geglu_bwd_kernel<float>, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)h, (const float*)dg, (float*)dh, rows, dff, d);
+  else
+    hipLaunchKernelGGL(geglu_bwd_kernel<bf16_t>, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)h, (const bf16_t*)dg, (bf16_t*)dh, rows, dff, d);
   MR_CHECK_LAUNCH("geglu_bwd");
   return MRMT3_OK;
 }
@@ -766,7 +771,8 @@ extern "C" int mrmt3_addpos_fwd(const void* src, int src_dtype, const float* pos
   return MRMT3_OK;
 }
 
-__global__ void dropmask_cast_kernel(const float* __restrict__ dx, bf16_t* __restrict__ out, size_t n4, DropCfg dc) {
+template <typename TO>
+__global__ void dropmask_cast_kernel(const float* __restrict__ dx, TO* __restrict__ out, size_t n4, DropCfg dc) {
   DROP_STEP(dc);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float a[4];
@@ -777,15 +783,19 @@ __global__ void dropmask_cast_kernel(const float* __restrict__ dx, bf16_t* __res
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] *= m[e];
     }
-    store4<bf16_t>(out + i * 4, a);
+    store4<TO>(out + i * 4, a);
   }
 }
 
-extern "C" int mrmt3_dropmask_cast(const float* dx, void* out_bf16, size_t n, float p_drop, uint64_t seed, const int32_t* step_dev,
-                                   uint32_t stream_id, void* stream) {
-  MR_CHECK_ARG(dx && out_bf16 && n % 4 == 0, "dropmask_cast: bad args");
-  hipLaunchKernelGGL(dropmask_cast_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dx,
-                     (bf16_t*)out_bf16, n / 4, make_drop(p_drop, seed, stream_id, step_dev));
+extern "C" int mrmt3_dropmask_cast(const float* dx, void* out, int out_dtype, size_t n, float p_drop, uint64_t seed,
+                                   const int32_t* step_dev, uint32_t stream_id, void* stream) {
+  MR_CHECK_ARG(dx && out && n % 4 == 0, "dropmask_cast: bad args");
+  if (out_dtype == MRMT3_F32)
+    hipLaunchKernelGGL(dropmask_cast_kernel<float>, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dx,
+                       (float*)out, n / 4, make_drop(p_drop, seed, stream_id, step_dev));
+  else
+    hipLaunchKernelGGL(dropmask_cast_kernel<bf16_t>, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dx,
+                       (bf16_t*)out, n / 4, make_drop(p_drop, seed, stream_id, step_dev));
   MR_CHECK_LAUNCH("dropmask_cast");
   return MRMT3_OK;
 }

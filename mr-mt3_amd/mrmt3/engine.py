@@ -69,6 +69,7 @@ class Engine:
         # lm_head (and the final decoder norm feeding it) in "bf16" (MFMA bf16 operands) or "f32" (exact-f32 MFMA on
         # the master weights; inference / parity only)
         self.head_dtype = "bf16"
+        self._wt32 = {}
         self._side = None
         self._side_dirty = False
         self._held = []
@@ -95,6 +96,20 @@ class Engine:
     def ln(self, key):
         return self.flat.master(key)
 
+    def WT(self, name):
+        """Transposed weight [in, out] for the data-gradient products: the pre-transposed bf16 copy, or — fp32 path — an
+        f32 transpose of the master made on demand (kept for one forward/backward pass: prepare() drops them, the AdamW
+        kernel rewrites the master without touching torch's version counters)."""
+        if self.dt == torch.bfloat16:
+            return self.flat.WT(name)
+        t = self._wt32.get(name)
+        if t is None:
+            w = self.flat.W(name, torch.float32)
+            t = torch.empty(w.shape[1], w.shape[0], device=w.device, dtype=torch.float32)
+            lib.transpose(w, t)
+            self._wt32[name] = t
+        return t
+
     def side_stream(self):
         if self._side is None or self._side.device != torch.cuda.current_stream().device:
             self._side = torch.cuda.Stream(priority=int(os.environ.get("MRMT3_WGRAD_PRIO", "-1")))
@@ -108,6 +123,8 @@ class Engine:
         One-by-one path (shapes the grouped kernel does not take): on the side stream, kept cheap on the host — events
         come from a small ring, the kernel is launched on the side stream directly, and the operands are kept alive by
         reference until the next join instead of `record_stream` bookkeeping."""
+        if a.dtype == torch.float32:                      # fp32 training / parity path: exact-f32 product, in place, now
+            return lib.gemm_tn_f32(a, b, out, accumulate=True)
         if self.tn_group is not None and self.tn_group.ok(a, b, out):
             return self.tn_group.add(a, b, out, accumulate=True)
         if not self.overlap_wgrad:
@@ -122,8 +139,20 @@ class Engine:
         self._side_dirty = True
 
     def _norm_bwd(self, *a, **kw):
-        """lib.add_rmsnorm_bwd with the norm-weight gradient deferred to one batched reduction (flush_norm_dw)."""
-        return lib.add_rmsnorm_bwd(*a, defer=self.norm_dw, **kw)
+        """lib.add_rmsnorm_bwd with the norm-weight gradient deferred to one batched reduction (flush_norm_dw).
+        fp32 path: the kernel's second output (the masked gradient of the sublayer output below) is bf16-only, so it is
+        formed from dx1 here — dx1 itself without dropout, one mask-and-copy launch with it."""
+        if self.dt == torch.bfloat16:
+            return lib.add_rmsnorm_bwd(*a, defer=self.norm_dw, **kw)
+        want_dy = kw.pop("want_dy", True)
+        dx1, _ = lib.add_rmsnorm_bwd(*a, defer=self.norm_dw, want_dy=False, **kw)
+        if not want_dy:
+            return dx1, None
+        p = kw.get("p", 0.0)
+        if p <= 0.0:
+            return dx1, dx1
+        return dx1, lib.dropmask_cast(dx1, p=p, seed=kw.get("seed", 0), stream_id=kw.get("stream_y", 0),
+                                      step=kw.get("step"), out_dtype=torch.float32)
 
     def flush_norm_dw(self):
         if self.norm_dw is not None:
@@ -162,8 +191,8 @@ class Engine:
     def prepare(self, training: bool):
         if self.dt == torch.bfloat16:
             self.flat.refresh_shadows(need_transposed=training)
-        elif training:
-            raise RuntimeError("backward is implemented for the bf16 compute path only")
+        else:
+            self._wt32 = {}
 
     # ---- one T5Stack (models/t5.py:507-702) ----------------------------------------------------------
     def stack_fwd(self, prefix, x, B, L, n_layers, is_decoder, enc=None, Le=0, p=0.0, tape=None, out_dtype=None):
@@ -256,10 +285,10 @@ class Engine:
             assert t["kind"] == "ff" and t["i"] == i
             ff = t["ff"]
             self.wgrad(dy, t["g"], f.GW(f"{prefix}.{i}.wo"))
-            dg = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.wo"))
+            dg = lib.gemm_nt(dy, self.WT(f"{prefix}.{i}.wo"))
             dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, step=self.step_dev, stream_id=t["s_g"])
             self.wgrad(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"))
-            dxn = lib.gemm_nt(dh, f.WT(f"{prefix}.{i}.wi"), out_dtype=self.y_dtype)
+            dxn = lib.gemm_nt(dh, self.WT(f"{prefix}.{i}.wi"), out_dtype=self.y_dtype)
             dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
                                          f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
                                          dx1=dx)
@@ -267,7 +296,7 @@ class Engine:
                 t = tape.pop()
                 assert t["kind"] == "cross"
                 self.wgrad(dy, t["o"], f.GW(f"{prefix}.{i}.co"))
-                do = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.co"))
+                do = lib.gemm_nt(dy, self.WT(f"{prefix}.{i}.co"))
                 dq = torch.empty_like(t["q"])
                 dkv = dkv_all[:, i * 2 * inner:(i + 1) * 2 * inner]
                 kv = t["kv"]
@@ -276,21 +305,21 @@ class Engine:
                              stream_id=t["s_att"], o_lo=t["o_lo"])
                 self.wgrad(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"))
                 self.wgrad(dkv, enc, f.GW(f"{prefix}.{i}.ckv"))
-                dxn = lib.gemm_nt(dq, f.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
+                dxn = lib.gemm_nt(dq, self.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
                 dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
                                              f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
                                              dx1=dx)
             t = tape.pop()
             assert t["kind"] == "self" and t["i"] == i
             self.wgrad(dy, t["o"], f.GW(f"{prefix}.{i}.o"))
-            do = lib.gemm_nt(dy, f.WT(f"{prefix}.{i}.o"))
+            do = lib.gemm_nt(dy, self.WT(f"{prefix}.{i}.o"))
             qkv = t["qkv"]
             dqkv = torch.empty_like(qkv)
             lib.attn_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], t["o"], do, t["lse"],
                          dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, H, L, L, is_dec, p=p,
                          seed=seed, step=self.step_dev, stream_id=t["s_att"], o_lo=t["o_lo"])
             self.wgrad(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"))
-            dxn = lib.gemm_nt(dqkv, f.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
+            dxn = lib.gemm_nt(dqkv, self.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
             last = i == 0                                     # the stack's input gradient leaves in f32
             dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
                                          f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed, step=self.step_dev,
@@ -298,7 +327,7 @@ class Engine:
             if on_layer_done is not None:
                 on_layer_done(prefix, i)
         if dkv_all is not None:
-            lib.gemm_nt(dkv_all, f.WT(f"{prefix}.ckv_all"), out=d_enc)          # d_enc is written here and nowhere else
+            lib.gemm_nt(dkv_all, self.WT(f"{prefix}.ckv_all"), out=d_enc)          # d_enc is written here and nowhere else
         return dx
 
     # ---- model pieces ------------------------------------------------------------------------------------
@@ -326,7 +355,7 @@ class Engine:
         dx = self.stack_bwd(tape, d_enc_out, on_layer_done=on_layer_done)
         t = tape.pop()
         assert t["kind"] == "enc_in"
-        dsrc = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, step=self.step_dev, stream_id=t["s_emb"])
+        dsrc = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, step=self.step_dev, stream_id=t["s_emb"], out_dtype=self.dt)
         self.wgrad(dsrc, t["mel"], self.flat.GW("proj"))
 
     def segmem(self, ids, B, L, tape=None):
@@ -389,19 +418,19 @@ class Engine:
             t = tape.pop()
             B, L, Ls = t["B"], t["L"], t["Ls"]
             pre, b = "segmem_encoder", "segmem_encoder.block.0.layer"
-            GW, WT = f.GW(f"{pre}.0.qkv"), f.WT(f"{pre}.0.qkv")
+            GW, WT = f.GW(f"{pre}.0.qkv"), self.WT(f"{pre}.0.qkv")
             d_out = d_mem.contiguous().view(B * Ls, d)
             dx2, dy2 = self._norm_bwd(d_out, None, t["x2"], t["rstd2"], self.ln(f"{pre}.final_layer_norm.weight"),
                                            f.grad(f"{pre}.final_layer_norm.weight"))
             self.wgrad(dy2, t["g"], f.GW(f"{pre}.0.wo"))
-            dg = lib.gemm_nt(dy2, f.WT(f"{pre}.0.wo"))
+            dg = lib.gemm_nt(dy2, self.WT(f"{pre}.0.wo"))
             dh = lib.geglu_bwd(t["h"], dg)
             self.wgrad(dh, t["xn1"], f.GW(f"{pre}.0.wi"))
-            dxn1 = lib.gemm_nt(dh, f.WT(f"{pre}.0.wi"), out_dtype=self.y_dtype)
+            dxn1 = lib.gemm_nt(dh, self.WT(f"{pre}.0.wi"), out_dtype=self.y_dtype)
             dx1, dy = self._norm_bwd(dxn1, dx2, t["x1"], t["rstd1"], self.ln(f"{b}.1.layer_norm.weight"),
                                           f.grad(f"{b}.1.layer_norm.weight"), dx1=dx2)
             self.wgrad(dy, t["o"], f.GW(f"{pre}.0.o"))
-            do = lib.gemm_nt(dy, f.WT(f"{pre}.0.o"))
+            do = lib.gemm_nt(dy, self.WT(f"{pre}.0.o"))
             kv = t["kv"]
             dq, dkv = torch.empty_like(t["q"]), torch.empty_like(kv)
             lib.attn_bwd(t["q"], kv[:, :inner], kv[:, inner:], t["o"], do, t["lse"], dq, dkv[:, :inner],
@@ -417,9 +446,9 @@ class Engine:
                                         self.ln(f"{b}.0.layer_norm.weight"), f.grad(f"{b}.0.layer_norm.weight"),
                                         want_dy=False)
         assert t["kind"] == "seg_in"
-        dsrc = lib.dropmask_cast(dx)
+        dsrc = lib.dropmask_cast(dx, out_dtype=self.dt)
         self.wgrad(dsrc, t["emb"], f.GW("segmem_proj"))
-        demb = lib.gemm_nt(dsrc, f.WT("segmem_proj"), out_dtype=torch.float32)
+        demb = lib.gemm_nt(dsrc, self.WT("segmem_proj"), out_dtype=torch.float32)
         lib.embed_bwd(t["ids"], demb, f.grad("decoder_embed_tokens.weight"), t["L"], shift=False,
                       pad_id=self.cfg["pad_token_id"])
 
@@ -507,16 +536,18 @@ class Engine:
         return logits.view(B, Ld, self.V), tape
 
     def backward(self, tape, dlogits, on_layer_done=None):
-        """dlogits: [B*Ld, V] (bf16 preferred; fp32 is cast).  Accumulates into flat.G."""
+        """dlogits: [B*Ld, V] in the compute dtype (anything else is cast).  Accumulates into flat.G.  With an fp32 engine
+        every product, the attention backward and the row-wise kernels run in exact f32 (the reference's own training
+        precision, config/config_slakh_segmem.yaml:47): slow, and the tight pin of this hand-written tape against autograd."""
         f, cfg, d = self.flat, self.cfg, self.d
         variant, Ls = self.variant, self.segmem_length
         t = tape.pop()
         assert t["kind"] == "head"
         dl = dlogits.reshape(-1, self.V)
-        if dl.dtype != torch.bfloat16:
+        if dl.dtype != self.dt:
             dl = self._act(dl)
         self.wgrad(dl, t["dec"], f.GW("lm_head"))
-        d_dec = lib.gemm_nt(dl, f.WT("lm_head"), out_dtype=torch.float32)
+        d_dec = lib.gemm_nt(dl, self.WT("lm_head"), out_dtype=torch.float32)
         if on_layer_done is not None:
             on_layer_done("lm_head", 0)
         # peek the decoder-input record (it sits below the decoder stack's records)
@@ -535,7 +566,8 @@ class Engine:
         start, pad = cfg["decoder_start_token_id"], cfg["pad_token_id"]
         d_mem = None
         if variant == "segmem_v1":
-            dxm = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, step=self.step_dev, stream_id=t["s_emb"]).float().view(B, Lx, d)
+            dxm = lib.dropmask_cast(dx, p=t["p"], seed=self.seed, step=self.step_dev, stream_id=t["s_emb"],
+                                    out_dtype=self.dt).float().view(B, Lx, d)
             d_mem = dxm[:, :Ls]
             lib.embed_bwd(t["labels"].view(-1), dxm[:, Ls:].contiguous().view(-1, d), table_g, Ld, shift=True,
                           start_id=start, pad_id=pad)

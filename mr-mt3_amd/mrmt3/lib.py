@@ -49,12 +49,15 @@ _SIGS = {
     "mrmt3_host_alloc": (vp, [C.c_size_t]),
     "mrmt3_host_free": (None, [vp]),
     "mrmt3_dispatch_counts": (ci, [vp, ci, ci]),
-    "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_geglu_bwd": (ci, [vp, vp, vp, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_gemm_tn_f32": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),
+    "mrmt3_attn_bwd_f32": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci,
+                                cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_bwd_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_embed_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp, csz, vp]),
     "mrmt3_addpos_fwd": (ci, [vp, ci, vp, vp, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
-    "mrmt3_dropmask_cast": (ci, [vp, vp, csz, cf, cu64, vp, cu32, vp]),
+    "mrmt3_dropmask_cast": (ci, [vp, vp, ci, csz, cf, cu64, vp, cu32, vp]),
     "mrmt3_ce_count": (ci, [vp, ci, ci, ci, ci, vp, vp]),
     "mrmt3_ce_fwd_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]),
     "mrmt3_lmhead_ce_fwd_bwd": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp, csz, ci, vp]),
@@ -99,6 +102,8 @@ def load():
             "(no CPU fallback). Run `python __graft_entry__.py` / `make -C mr-mt3_amd/csrc` first.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
+        if os.environ.get("MRMT3_TOOL_LIB") and not hasattr(lib, name):
+            continue                       # tuning only: an older variant build under A/B may lack newer entry points
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -125,9 +130,10 @@ PROFILE = None
 
 
 class _Timed:
-    def __init__(self, family, work, unit, stream=None):
+    def __init__(self, family, work, unit, stream=None, executed=None):
         self.args = (family, work, unit)
         self.stream = stream
+        self.executed = executed     # optional second price of the same launch (family "<name>@executed")
 
     def __enter__(self):
         if PROFILE is not None:
@@ -140,6 +146,8 @@ class _Timed:
         if PROFILE is not None:
             self.e1.record(self.stream) if self.stream is not None else self.e1.record()
             PROFILE.append(self.args + (self.e0, self.e1))
+            if self.executed is not None:
+                PROFILE.append((self.args[0] + "@executed", self.executed, self.args[2], self.e0, self.e1))
         return False
 
 
@@ -418,6 +426,19 @@ class TnGroup:
         self.last_info = ent["info"]
 
 
+def gemm_tn_f32(a, b, out, accumulate=False):
+    """out[N1,N2] (+)= a[M,N1]^T @ b[M,N2], everything f32 (the fp32 training / parity path)."""
+    _dev(a, b, out)
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    assert b.shape[0] == M and tuple(out.shape) == (N1, N2)
+    assert a.dtype == b.dtype == out.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    with _Timed("gemm_tn_f32", 2.0 * M * N1 * N2, "FLOP"):
+        _check(load().mrmt3_gemm_tn_f32(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N1, N2,
+                                        int(accumulate), _stream()), "gemm_tn_f32")
+    return out
+
+
 def gemm_tn(a, b, out, accumulate=False, stream=None, defer=None):
     """out[N1,N2] (+)= a[M,N1]^T @ b[M,N2]  (bf16 in, f32 out).  `stream` (torch.cuda.Stream) launches there
     instead of on the current stream, without the cost of a stream context switch.  `defer=` a TnBatch: only the
@@ -521,6 +542,17 @@ def add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, want_dy=True, p=0.0, seed=0, str
     return dx1, dy
 
 
+def _attn_executed_pairs(Lq, Lk, causal):
+    """(query, key) pairs the flash kernels visit: 128-query tiles x 64-key tiles, causal tiles above the diagonal skipped."""
+    if not causal:
+        return float(Lq) * Lk
+    n = 0
+    for q0 in range(0, Lq, 128):
+        n_kv = min(-(-Lk // 64), min(q0 + 127, Lq - 1) // 64 + 1)
+        n += min(128, Lq - q0) * min(Lk, n_kv * 64)
+    return float(n)
+
+
 def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse=True, step=None, want_lo=None):
     """q: [B*Lq, ldq-view], k/v: [B*Lk, ld-view] 2-D views whose column 0 is head 0 / dim 0.
     want_lo (True / False instead of None): returns (o, lse, o_lo) with o_lo = bf16(O - bf16(O)) for the backward's
@@ -530,7 +562,7 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse
     o_lo = torch.empty_like(o) if want_lo and q.dtype == torch.bfloat16 else None
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
     # algorithmic FLOPs count the full (unskipped) square, as the reference computes it
-    with _Timed("attn_fwd", 4.0 * B * H * Lq * Lk * 64, "FLOP"):
+    with _Timed("attn_fwd", 4.0 * B * H * Lq * Lk * 64, "FLOP", executed=4.0 * B * H * 64 * _attn_executed_pairs(Lq, Lk, causal)):
         _check(load().mrmt3_attn_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
                                      _p(o_lo), _p(lse), B, H, Lq, Lk, int(causal), _dt(q), p, seed, _p(step), stream_id,
                                      _stream()),
@@ -544,7 +576,14 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal, p=0.0, seed
     _dev(q, k, v, o, d_o, lse, dq, dk, dv, o_lo)
     assert o_lo is None or (o_lo.shape == o.shape and o_lo.stride(0) == o.stride(0))
     delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    with _Timed("attn_bwd", 8.0 * B * H * Lq * Lk * 64, "FLOP"):
+    if q.dtype == torch.float32:                     # exact-f32 path (fp32 training / parity)
+        assert all(t.dtype == torch.float32 for t in (k, v, o, d_o, dq, dk, dv))
+        _check(load().mrmt3_attn_bwd_f32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                         _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk),
+                                         dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, int(causal), p, seed,
+                                         _p(step), stream_id, _stream()), "attn_bwd_f32")
+        return dq, dk, dv
+    with _Timed("attn_bwd", 8.0 * B * H * Lq * Lk * 64, "FLOP", executed=8.0 * B * H * 64 * _attn_executed_pairs(Lq, Lk, causal)):
         _check(load().mrmt3_attn_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
                                      _p(o_lo), _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(dq), dq.stride(0), _p(dk),
                                      dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, int(causal), p, seed,
@@ -579,7 +618,8 @@ def geglu_bwd(h, dg, p=0.0, seed=0, stream_id=0, step=None):
     _dev(h, dg)
     rows, two = h.shape
     dh = torch.empty_like(h)
-    _check(load().mrmt3_geglu_bwd(_p(h), _p(dg), _p(dh), rows, two // 2, p, seed, _p(step), stream_id, _stream()),
+    assert dg.dtype == h.dtype
+    _check(load().mrmt3_geglu_bwd(_p(h), _p(dg), _p(dh), rows, two // 2, _dt(h), p, seed, _p(step), stream_id, _stream()),
            "geglu_bwd")
     return dh
 
@@ -613,10 +653,10 @@ def addpos_fwd(src, pos, seq_len, pos_offset=0, p=0.0, seed=0, stream_id=0, step
     return x
 
 
-def dropmask_cast(dx, p=0.0, seed=0, stream_id=0, step=None):
+def dropmask_cast(dx, p=0.0, seed=0, stream_id=0, step=None, out_dtype=torch.bfloat16):
     _dev(dx)
-    out = torch.empty(dx.shape, device=dx.device, dtype=torch.bfloat16)
-    _check(load().mrmt3_dropmask_cast(_p(dx), _p(out), dx.numel(), p, seed, _p(step), stream_id, _stream()),
+    out = torch.empty(dx.shape, device=dx.device, dtype=out_dtype)
+    _check(load().mrmt3_dropmask_cast(_p(dx), _p(out), _dt(out), dx.numel(), p, seed, _p(step), stream_id, _stream()),
            "dropmask_cast")
     return out
 

@@ -86,10 +86,15 @@ class Trainer:
         eng.reset_deferred()                                 # nothing of an aborted capture / failed step leaks into this one
         eng._stream_ctr = 0                                  # dropout site ids are per-step (step_dev salts them)
         mel = self.mel_from_audio(inputs) if audio else inputs
-        dec, tape = eng.forward(mel, labels, targets_prev, training=True, need_grad=True, want_logits=False)
-        # lm_head + CE over row chunks: the f32 logits exist one chunk at a time in a cache-sized workspace
-        loss, dl = lib.lmhead_cross_entropy(dec, eng.W("lm_head"), labels.reshape(-1), want_grad=True,
-                                            grad_dtype=torch.bfloat16, weighted=self.weighted)
+        if eng.dt == torch.bfloat16:
+            dec, tape = eng.forward(mel, labels, targets_prev, training=True, need_grad=True, want_logits=False)
+            # lm_head + CE over row chunks: the f32 logits exist one chunk at a time in a cache-sized workspace
+            loss, dl = lib.lmhead_cross_entropy(dec, eng.W("lm_head"), labels.reshape(-1), want_grad=True,
+                                                grad_dtype=torch.bfloat16, weighted=self.weighted)
+        else:                                                # fp32 engine (`precision: 32`): exact-f32 lm_head, then CE
+            logits, tape = eng.forward(mel, labels, targets_prev, training=True, need_grad=True)
+            loss, dl = lib.cross_entropy(logits.view(-1, logits.shape[-1]), labels.reshape(-1), want_grad=True,
+                                         grad_dtype=torch.float32, weighted=self.weighted)
         flat.G.zero_()
         self.buckets.reset()
         if cut is None:
@@ -267,6 +272,10 @@ class Trainer:
     def eval_loss(self, inputs, labels, targets_prev=None, audio: bool = False):
         self.model.eval()
         mel = self.mel_from_audio(inputs) if audio else inputs
+        if self.engine.dt != torch.bfloat16:
+            logits, _ = self.engine.forward(mel, labels, targets_prev, training=False, need_grad=False)
+            return lib.cross_entropy(logits.view(-1, logits.shape[-1]), labels.reshape(-1), want_grad=False,
+                                     weighted=self.weighted)[0]
         dec, _ = self.engine.forward(mel, labels, targets_prev, training=False, need_grad=False, want_logits=False)
         loss, _ = lib.lmhead_cross_entropy(dec, self.engine.W("lm_head"), labels.reshape(-1), want_grad=False,
                                            weighted=self.weighted)

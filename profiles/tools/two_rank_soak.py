@@ -31,6 +31,35 @@ def worker(rank, mode, iters, port, graph):
     if mode == "ddp":
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
         dist.init_process_group("gloo", rank=rank, world_size=2)
+    # MRMT3_SOAK_TRACE=1: an exact (integer, order-independent) checksum of the output of every kernel wrapper of
+    # mrmt3.lib, of the weights, their bf16 shadows and transposed copies after every step: the FIRST checksum that
+    # differs from the first repetition's names the kernel that produced different bits
+    trace = os.environ.get("MRMT3_SOAK_TRACE") == "1"
+    log = []
+    if trace:
+        from mrmt3 import lib as L
+
+        def bits(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            v = t.view(torch.int16) if t.element_size() == 2 else (t.view(torch.int32) if t.element_size() == 4 else t.view(torch.int64))
+            return v.sum(dtype=torch.int64)
+
+        def wrap(name):
+            fn = getattr(L, name)
+
+            def inner(*a, **kw):
+                out = fn(*a, **kw)
+                outs = out if isinstance(out, (tuple, list)) else (out,)
+                for j, o in enumerate(outs):
+                    if isinstance(o, torch.Tensor) and o.is_cuda:
+                        log.append(("%s[%d] %s" % (name, j, tuple(o.shape)), bits(o)))
+                return out
+            setattr(L, name, inner)
+        for nm in ("logmel", "gemm_nt", "add_rmsnorm_fwd", "attn_fwd", "geglu_fwd", "gemm_nt_geglu", "embed_fwd", "addpos_fwd",
+                   "lmhead_cross_entropy", "cross_entropy", "add_rmsnorm_bwd", "attn_bwd", "geglu_bwd", "dropmask_cast", "cast"):
+            wrap(nm)
     w = golden_weights(T5_SMALL)
     audio = torch.from_numpy(synth_audio(2, seed=50 + rank)).to(dev)
     lab = torch.from_numpy(synth_labels(2, 128, seed=60 + rank)).to(dev)
@@ -46,23 +75,48 @@ def worker(rank, mode, iters, port, graph):
             with torch.no_grad():
                 m.flat.P.mul_(1.5)
         tr = Trainer(m, lr=1e-3, graph=graph)
-        for _ in range(5):
-            tr.train_step(audio, lab, audio=True)
+        cur = []
+        del log[:]
+        for st_ in range(5):
+            loss = tr.train_step(audio, lab, audio=True)
+            cur.append((m.flat.G.clone(), loss.clone()))         # the gradient of every step (before AdamW spreads a glitch)
+            if trace:
+                log.append(("step %d: G" % st_, bits(m.flat.G)))
+                log.append(("step %d: P after AdamW" % st_, bits(m.flat.P)))
+                log.append(("step %d: bf16 shadow" % st_, bits(m.flat.S)))
+                log.append(("step %d: transposed shadow" % st_, bits(m.flat.ST)))
+                log.append(("step %d: AdamW m" % st_, bits(m.flat.M)))
+                log.append(("step %d: AdamW v" % st_, bits(m.flat.V)))
         torch.cuda.synchronize()
-        cur = (m.flat.G.clone(), m.flat.P.clone())
+        if trace:
+            names = [n for n, _ in log]
+            vec = torch.stack([v for _, v in log]).cpu()
+            if first is None:
+                first_vec, first_names = vec, names
+            elif names != first_names or not torch.equal(vec, first_vec):
+                j = next((i for i in range(min(len(names), len(first_names))) if names[i] != first_names[i] or vec[i] != first_vec[i]), -1)
+                print("rank %d iteration %d: first differing checksum is #%d of %d: %s  (previous ops: %s)" % (
+                    rank, it, j, len(names), names[j] if j >= 0 else "?", " <- ".join(names[max(0, j - 3):j][::-1])), flush=True)
         if first is None:
             first = cur
-        elif not (torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])):
-            bad += 1
-            rep = []
-            for key in m.flat.shapes:
-                a, b = m.flat.view(cur[0], key), m.flat.view(first[0], key)
-                n = int((a != b).sum().item())
-                if n:
-                    rep.append("%s: %d elements, max|d| %.3e" % (key, n, (a - b).abs().max().item()))
-            print("rank %d iteration %d DIFFERS from iteration 0: %s" % (rank, it, "; ".join(rep[:12]) +
-                                                                        (" ... (%d tensors)" % len(rep) if len(rep) > 12 else "")), flush=True)
-        del tr, m
+        else:
+            for st, ((g, l), (g0, l0)) in enumerate(zip(cur, first)):
+                if torch.equal(g, g0):
+                    continue
+                bad += 1
+                same, diff = [], []
+                for key in m.flat.shapes:
+                    a, b = m.flat.view(g, key), m.flat.view(g0, key)
+                    n = int((a != b).sum().item())
+                    (diff if n else same).append((key, n, (a - b).abs().max().item() if n else 0.0))
+                short = lambda k: k.replace(".weight", "").replace("block.", "").replace("layer.", "").replace("SelfAttention", "sa").replace("EncDecAttention", "ca").replace("DenseReluDense", "ff")
+                print("rank %d iteration %d: gradient of step %d DIFFERS (loss %.7f vs %.7f); %d tensors differ, %d identical.\n"
+                      "   differing: %s\n   identical: %s" % (
+                          rank, it, st, l.item(), l0.item(), len(diff), len(same),
+                          "; ".join("%s %d (%.1e)" % (short(k), n, d) for k, n, d in diff[:200]),
+                          ", ".join(short(k) for k, _, _ in same[:200])), flush=True)
+                break
+        del tr, m, cur
     print("rank %d mode %s graph %d: %d iterations, %d differing from the first, %.1f s" % (rank, mode, graph, iters, bad, time.time() - t0),
           flush=True)
     if mode == "ddp":

@@ -87,7 +87,9 @@ def test_bench_shape_loss_logits_and_every_gradient_vs_oracle(variant):
     counts = lib.dispatch_counts()
     print(variant, "dispatch:", counts, "grouped weight-gradient items:", eng.tn_group.last_info.n_items)
     # the kernels of the benchmark step really ran: ping-pong NT, fused wi + GEGLU, grouped weight gradients
-    assert counts["gemm_nt8"] >= 100 and counts["gemm_nt_geglu"] >= 16, counts
+    # (at 16 segments the dispatch rule gives the ping-pong kernel 57 of the step's NT products — both its 256-row and
+    # its 128-row form — and the others to the tile kernel; at 64 segments it is 113 of 161, same kernels)
+    assert counts["gemm_nt8"] >= 40 and counts["gemm_nt_geglu"] >= 16, counts
     assert counts["tn_group"] >= 1 and eng.tn_group.last_info.n_items > 0, counts
     assert counts["attn_fwd"] >= 24 and counts["attn_bwd"] + counts["attn_bwd_onepass"] >= 24, counts
 

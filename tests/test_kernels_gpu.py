@@ -383,6 +383,45 @@ def test_attn_bwd_bf16(dev, B, H, Lq, Lk, causal):
     assert _rel(dv, vr.grad) < 2e-2, _rel(dv, vr.grad)
 
 
+@pytest.mark.parametrize("B,H,Lq,p", [(2, 6, 1024, 0.0), (2, 6, 256, 0.1), (1, 3, 1000, 0.1), (3, 2, 45, 0.0)])
+def test_attn_bwd_onepass_matches_autograd_and_the_two_pass_kernels(dev, monkeypatch, B, H, Lq, p):
+    """The one-pass backward (attention_onepass.hip: 256 keys, not causal — the decoder's cross-attention and the
+    encoder's self-attention) against f32 autograd of the same dropped attention, and against the two-pass kernels on
+    the same inputs (same masks, same bf16 operand roundings: only summation orders differ)."""
+    from mrmt3 import lib
+    Lk = 256
+    g = torch.Generator(device="cpu").manual_seed(Lq * 3 + int(p * 100))
+    q = (torch.randn(B * Lq, H * 64, generator=g) * 0.35).to(dev).bfloat16()
+    k = torch.randn(B * Lk, H * 64, generator=g).to(dev).bfloat16()
+    v = torch.randn(B * Lk, H * 64, generator=g).to(dev).bfloat16()
+    d_o = torch.randn(B * Lq, H * 64, generator=g).to(dev).bfloat16()
+    o, lse, o_lo = lib.attn_fwd(q, k, v, B, H, Lq, Lk, False, p=p, seed=31, stream_id=4, want_lo=True)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MRMT3_ATTN_ONEPASS", mode)
+        monkeypatch.setenv("MRMT3_ATTN_ONEPASS_MIN_BH", "1")
+        dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+        before = lib.dispatch_counts()
+        lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, False, p=p, seed=31, stream_id=4, o_lo=o_lo)
+        after = lib.dispatch_counts()
+        assert after["attn_bwd_onepass"] - before["attn_bwd_onepass"] == int(mode == "1")
+        assert after["attn_bwd"] - before["attn_bwd"] == int(mode == "0")
+        res[mode] = (dq, dk, dv)
+    # f32 autograd of the dropped attention (mask from the restatement of the generator)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    qh = qr.view(B, Lq, H, 64).transpose(1, 2); kh = kr.view(B, Lk, H, 64).transpose(1, 2); vh = vr.view(B, Lk, H, 64).transpose(1, 2)
+    pr = torch.softmax(qh @ kh.transpose(2, 3), -1)
+    if p > 0:
+        from oracle import dropout_ref as dr
+        keep, scale = dr.attn_keep_mask(B, H, Lq, Lk, p, 31, 4)
+        pr = pr * torch.from_numpy(keep).to(dev) * scale
+    ((pr @ vh).transpose(1, 2).reshape(B * Lq, H * 64) * d_o.float()).sum().backward()
+    for name, got1, got0, ref in zip(("dq", "dk", "dv"), res["1"], res["0"], (qr.grad, kr.grad, vr.grad)):
+        assert torch.isfinite(got1.float()).all(), name
+        assert _rel(got1, ref) < 2e-2, (name, _rel(got1, ref))
+        assert _rel(got1, got0) < 6e-3, (name, "one-pass vs two-pass", _rel(got1, got0))
+
+
 def test_attn_online_softmax_rescale_branch(dev):
     """Force the running max to jump at a late key tile (one key spiked against one query)."""
     from mrmt3 import lib
@@ -512,6 +551,78 @@ def test_attn_f32(dev, B, H, Lq, Lk, causal):
     o, lse = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal)
     oref, lref = _attn_ref(q, k, v, B, H, Lq, Lk, causal)
     assert torch.allclose(o, oref, atol=2e-5, rtol=1e-5) and torch.allclose(lse, lref, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", [(2, 6, 256, 256, False), (1, 6, 128, 128, True), (1, 3, 100, 320, False)])
+def test_attn_bwd_f32_matches_autograd(dev, B, H, Lq, Lk, causal):
+    """mrmt3_attn_bwd_f32 (the fp32 training / parity path) against torch autograd of softmax(q k^T) v in f32."""
+    from mrmt3 import lib
+    q = (torch.randn(B * Lq, H * 64, device=dev) * 0.35).requires_grad_(True)
+    k = torch.randn(B * Lk, H * 64, device=dev).requires_grad_(True)
+    v = torch.randn(B * Lk, H * 64, device=dev).requires_grad_(True)
+    d_o = torch.randn(B * Lq, H * 64, device=dev)
+    oref, _ = _attn_ref(q, k, v, B, H, Lq, Lk, causal)
+    oref.backward(d_o)
+    o, lse = lib.attn_fwd(q.detach(), k.detach(), v.detach(), B, H, Lq, Lk, causal)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib.attn_bwd(q.detach(), k.detach(), v.detach(), o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal)
+    for got, ref, name in ((dq, q.grad, "dq"), (dk, k.grad, "dk"), (dv, v.grad, "dv")):
+        assert _rel(got, ref) < 2e-5, (name, _rel(got, ref))
+
+
+def test_attn_f32_dropout_is_the_bf16_kernels_mask_and_consistent_forward_to_backward(dev):
+    """The f32 attention kernels draw the mask of the bf16 ones (oracle/dropout_ref.attn_keep_mask): uniform scores and
+    V = I expose it in the forward output; dV = Pd^T dO must follow the same mask."""
+    from mrmt3 import lib
+    from oracle import dropout_ref as dr
+    B, H, Lq, Lk, p, seed, stream = 2, 2, 48, 64, 0.1, 77, 3
+    q = torch.zeros(B * Lq, H * 64, device=dev)
+    k = torch.zeros(B * Lk, H * 64, device=dev)
+    v = torch.eye(64, device=dev).repeat(B, H)
+    o, lse = lib.attn_fwd(q, k, v, B, H, Lq, Lk, False, p=p, seed=seed, stream_id=stream)
+    keep, scale = dr.attn_keep_mask(B, H, Lq, Lk, p, seed, stream)
+    got = o.view(B, Lq, H, 64).permute(0, 2, 1, 3).cpu().numpy()
+    assert ((got != 0) == keep).all() and abs(got.max() - scale / Lk) < 1e-6
+    d_o = torch.ones_like(o)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, False, p=p, seed=seed, stream_id=stream)
+    want = (keep * (scale / Lk)).sum(2)                                       # [B, H, Lk]
+    assert np.abs(dv.view(B, Lk, H, 64)[..., 0].permute(0, 2, 1).cpu().numpy() - want).max() < 1e-5
+
+
+@pytest.mark.parametrize("M,N1,N2", [(512, 512, 384), (1000, 384, 512), (130, 1536, 512), (64, 70, 36)])
+def test_gemm_tn_f32(dev, M, N1, N2):
+    from mrmt3 import lib
+    a = torch.randn(M, N1, device=dev)
+    b = torch.randn(M, N2, device=dev)
+    c0 = torch.randn(N1, N2, device=dev)
+    c = c0.clone()
+    lib.gemm_tn_f32(a, b, c, accumulate=True)
+    ref = c0.double() + a.double().t() @ b.double()
+    assert _rel(c, ref.float()) < 2e-6
+    lib.gemm_tn_f32(a[:, :N1 - 2], b[:, 1:], c[:N1 - 2, 1:], accumulate=False)         # strided views, ragged tile edges
+    assert _rel(c[:N1 - 2, 1:], (a[:, :N1 - 2].double().t() @ b[:, 1:].double()).float()) < 2e-6
+    assert lib.dispatch_counts()["tn_f32"] >= 2
+
+
+def test_geglu_bwd_and_dropmask_cast_f32(dev):
+    from mrmt3 import lib
+    h = torch.randn(300, 2048, device=dev).requires_grad_(True)
+    dg = torch.randn(300, 1024, device=dev)
+    (_gelu_new(h[:, :1024]) * h[:, 1024:] * dg).sum().backward()
+    dh = lib.geglu_bwd(h.detach(), dg)
+    assert dh.dtype == torch.float32 and _rel(dh, h.grad) < 2e-6
+    # with dropout: the f32 forward's mask
+    g = lib.geglu_fwd(h.detach(), p=0.1, seed=5, stream_id=9)
+    dh2 = lib.geglu_bwd(h.detach(), dg, p=0.1, seed=5, stream_id=9)
+    kept = (g != 0).float()
+    h2 = h.detach().clone().requires_grad_(True)
+    (_gelu_new(h2[:, :1024]) * h2[:, 1024:] * dg * kept / 0.9).sum().backward()
+    assert _rel(dh2, h2.grad) < 1e-3
+    x = torch.randn(64, 512, device=dev)
+    a = lib.dropmask_cast(x, p=0.1, seed=1, stream_id=2, out_dtype=torch.float32)
+    b = lib.dropmask_cast(x, p=0.1, seed=1, stream_id=2)
+    assert a.dtype == torch.float32 and torch.equal(a.bfloat16(), b) and torch.equal(lib.dropmask_cast(x, out_dtype=torch.float32), x)
 
 
 # ---- gated GELU, embedding, CE, AdamW ------------------------------------------------------------------
