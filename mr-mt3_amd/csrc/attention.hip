@@ -393,8 +393,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
 // ------------------------------------------------------------------------------------------------
 // backward: dQ.  workgroup = 128 queries (wave = 32, query on the lane), loop over 64-key tiles
 // ------------------------------------------------------------------------------------------------
+// Three workgroups per CU (<= 168 VGPRs; the causal + dropout instantiation spills 4 registers outside the loop): the
+// kernel waits on dependent LDS-read -> MFMA -> exp chains more than it issues, and a third wave per SIMD measured
+// -4 % on the decoder's self-attention backward (profiles/r03_attn_micro.txt).  The dK/dV kernel stays at two: at 168
+// registers it spills 39 and runs 1.6x slower.
 template <bool PAIR, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
@@ -780,9 +784,10 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
-  const dim3 grid(attn_grid_x(Lq, causal), H, B);
-  if (causal && P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, P);
-  else if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, P);
+  const bool pair = attn_paired(Lq, causal, H, B);
+  const dim3 grid(attn_grid_x(Lq, pair), H, B);
+  if (pair && P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, P);
+  else if (pair) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, P);
   else if (P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_fwd");
@@ -808,16 +813,22 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
   hipStream_t s = (hipStream_t)stream;
+  if (mrmt3_attn_bwd_onepass_try(P, s)) {      // all keys of a (batch, head) in one workgroup: dQ, dK, dV in one pass
+    MR_CHECK_LAUNCH("attn_bwd onepass");
+    mrmt3_count(MRMT3_CNT_ATTN_BWD_ONEPASS);
+    return MRMT3_OK;
+  }
   // dQ first: it derives delta = rowsum(dO * O) from operands it loads anyway and leaves it for dK/dV
-  const dim3 gq(attn_grid_x(Lq, causal), H, B), gk(attn_grid_x(Lk, causal), H, B);
+  const bool pair_q = attn_paired(Lq, causal, H, B), pair_k = attn_paired(Lk, causal, H, B);
+  const dim3 gq(attn_grid_x(Lq, pair_q), H, B), gk(attn_grid_x(Lk, pair_k), H, B);
   const bool drop = P.drop.thresh8 != 0;
-  if (causal && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, dim3(256), 0, s, P);
-  else if (causal) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), 0, s, P);
+  if (pair_q && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, dim3(256), 0, s, P);
+  else if (pair_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), 0, s, P);
   else if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dq");
-  if (causal && drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, true>), gk, dim3(256), 0, s, P);
-  else if (causal) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, false>), gk, dim3(256), 0, s, P);
+  if (pair_k && drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, true>), gk, dim3(256), 0, s, P);
+  else if (pair_k) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, false>), gk, dim3(256), 0, s, P);
   else if (drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, true>), gk, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, false>), gk, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dkdv");

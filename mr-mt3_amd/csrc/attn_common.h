@@ -131,10 +131,16 @@ __device__ __forceinline__ void attn_tile(int& tile, int& h, int& b) {
   h = bh % H;
   b = bh / H;
 }
-// causal launches pair the 128-row tiles (see the kernels): ceil(n/2) workgroups along x
-static inline int attn_grid_x(int L, int causal) {
+// causal launches pair the 128-row tiles (see the kernels): ceil(n/2) workgroups along x — when that still leaves a few
+// workgroups per CU.  A small batch (12 segments x 6 heads: 288 pairs for 512-768 resident workgroup slots) runs the
+// tiles unpaired instead: twice the workgroups, unequal (2..16 key tiles each) but all resident at once.
+static inline bool attn_paired(int L, int causal, int H, int B) {
   const int n = ceil_div(L, 128);
-  return causal ? (n + 1) / 2 : n;
+  return causal && n >= 2 && ((n + 1) / 2) * H * B >= 512;
+}
+static inline int attn_grid_x(int L, bool paired) {
+  const int n = ceil_div(L, 128);
+  return paired ? (n + 1) / 2 : n;
 }
 // K/V (Q/dO) tiles are staged with buffer_load ... lds: the per-lane byte offset inside an 8-row group is constant
 // for the whole kernel, the tile offset is a scalar, and rows past the end of the tensor (or a whole tile that is
@@ -151,3 +157,6 @@ __device__ __forceinline__ void blds_rows8(__amdgpu_buffer_rsrc_t r, unsigned la
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, lane_off, tile_byte_off, 0, 0);
 }
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// attention_onepass.hip: the backward in one pass when a workgroup can own all keys of a (batch, head); 1 = launched
+int mrmt3_attn_bwd_onepass_try(const AttnParams& P, hipStream_t s);

@@ -469,19 +469,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
 // Returns 1 if the shape was launched on the second-generation kernel, 0 if the caller should use gemm.hip's.
 int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        int out_dtype, int accumulate, hipStream_t s) {
-  int min_m = 4096;
+  int min_m = 2048;
   { const char* e = getenv("MRMT3_GEMM8_MIN_M"); if (e && atoi(e) >= 128) min_m = atoi(e); }      // tuning only
   if (M < min_m || N < 256 || N % 128 != 0 || K % 128 != 0 || K < 128) return 0;      // (an even number of K steps)
-  // Shapes this kernel is measured to win on (profiles/r02_gemm_ab.txt).  Not: a last column tile that is half
-  // overlap (N % 256 == 128: qkv 1152, cq 384 — 11-33 % of the MFMAs redone), a tile count that leaves a fractional
-  // wave of workgroups (ckv: 384 tiles on 256 CUs), the accumulate form (one launch per decoder layer).
+  // Which shapes: measured COLD (profiles/r03_gemm_ab_cold.txt: 512 MiB written before every launch, as inside the
+  // training step — the back-to-back table of round 2 re-read operands out of the Infinity Cache and flattered round
+  // 1's kernel on the N % 256 == 128 shapes).  This kernel wins wherever its tiles come in whole waves of workgroups:
+  // at most one wave (short inputs: 12 segments per GPU, the encoder), or a tile count that fills >= 80 % of the
+  // last wave's slots.  A last column tile that is half overlap (N = 384 / 1152: 11-33 % of the MFMAs redone) still
+  // wins cold (qkv 115 -> 96 us).  Not: the accumulate form (one launch per decoder layer).
   {
     const char* force = getenv("MRMT3_GEMM8_ALL");             // tuning: take every admissible shape
     if (!(force && force[0] == '1')) {
-      if (N % 256 != 0 || accumulate) return 0;
-      const int cu = g8_cus() & ~7, t256 = ceil_div(M, 256) * (N / 256);
-      const int nt = t256 < cu ? ceil_div(M, 128) * (N / 256) : t256;
-      if (nt % cu != 0 && nt < 6 * cu) return 0;
+      if (accumulate) return 0;
+      const int cu = g8_cus() & ~7, tn = ceil_div(N, 256), t256 = ceil_div(M, 256) * tn;
+      const int nt = t256 < cu ? ceil_div(M, 128) * tn : t256;
+      const int waves = ceil_div(nt, cu);
+      if (nt > cu && nt * 5 < waves * cu * 4) return 0;        // a last wave of workgroups less than 80 % full
     }
   }
   if (((size_t)M * lda + K) * 2 >= 0x7FFF0000ull || ((size_t)N * ldb + K) * 2 >= 0x7FFF0000ull) return 0;

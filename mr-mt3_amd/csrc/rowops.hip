@@ -121,14 +121,20 @@ extern "C" int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype
 
 // backward: each workgroup owns NB_ROWS consecutive rows (wave w takes rows w, w+4, ...), keeps the
 // per-column dw partial sums in registers and issues one f32 atomic per column at the end.
-#define NB_ROWS 32
+// rows per workgroup: 32 for the tall decoder shapes (2048 workgroups at 65536 rows), fewer for shorter inputs so that
+// a launch still has >= ~2048 workgroups (12 segments per GPU: 12288 rows ran 384 workgroups at 3.1 TB/s of 6-7)
+static inline int nb_rows(int rows) {
+  int r = 32;
+  while (r > 4 && rows / r < 2048) r >>= 1;
+  return r;
+}
 template <int NV, typename TG, typename TRI, typename TRO>
 __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restrict__ dxn, const TRI* __restrict__ dres,
                                                               const float* __restrict__ x1, const float* __restrict__ rstd_in,
                                                               const float* __restrict__ w, TRO* __restrict__ dx1,
                                                               bf16_t* __restrict__ dy, float* __restrict__ dw_part, int rows,
                                                               int cols, DropCfg ddy, DropCfg dout, int out_drop,
-                                                              int* __restrict__ dw_counters) {
+                                                              int* __restrict__ dw_counters, int nb_rows_) {
   DROP_STEP(ddy); DROP_STEP(dout);
   __shared__ float red[4 * 256 * NV];  // [wave][col]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
     for (int e = 0; e < 4; ++e) dwp[i][e] = 0.f;
     if (i < nv) load4<float>(w + i * 256 + lane * 4, wv[i]);
   }
-  const int row_end = min(rows, (int)(blockIdx.x + 1) * NB_ROWS);
-  for (int row = blockIdx.x * NB_ROWS + wave; row < row_end; row += 4) {
+  const int row_end = min(rows, (int)(blockIdx.x + 1) * nb_rows_);
+  for (int row = blockIdx.x * nb_rows_ + wave; row < row_end; row += 4) {
     const size_t base = (size_t)row * cols;
     const float rstd = rstd_in[row];
     float g[NV][4], xh[NV][4], rr[NV][4];
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256) void dw_reduce_sites_kernel(const unsigned lon
   dw_reduce_body(part, (float*)dws[site], n_part, cols, scratch, (int*)(scratch + (size_t)DW_CHUNKS * cols));
 }
 
-extern "C" int mrmt3_add_rmsnorm_bwd_partial_rows(int rows) { return ceil_div(rows, NB_ROWS); }
+extern "C" int mrmt3_add_rmsnorm_bwd_partial_rows(int rows) { return ceil_div(rows, nb_rows(rows)); }
 
 extern "C" int mrmt3_norm_dw_reduce(const void* workspaces, const void* dws, const int* partial_rows, int n_sites, int cols,
                                     void* stream) {
@@ -307,7 +313,7 @@ extern "C" int mrmt3_norm_dw_reduce(const void* workspaces, const void* dws, con
 
 extern "C" size_t mrmt3_add_rmsnorm_bwd_workspace_bytes(int rows, int cols) {
   // per-workgroup partial rows | DW_CHUNKS chunk sums | one arrival counter per 64 columns
-  return ((size_t)ceil_div(rows, NB_ROWS) + DW_CHUNKS) * cols * sizeof(float) + (size_t)ceil_div(cols, 64) * sizeof(int);
+  return ((size_t)ceil_div(rows, nb_rows(rows)) + DW_CHUNKS) * cols * sizeof(float) + (size_t)ceil_div(cols, 64) * sizeof(int);
 }
 
 extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void* dres, int dres_dtype, const float* x1,
@@ -320,16 +326,17 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
                "add_rmsnorm_bwd: workspace too small");
   // workspace without dw: the partial rows are left for mrmt3_norm_dw_reduce (deferred, batched over sites)
   float* dw_part = (float*)workspace;
-  float* dw_scratch = workspace ? dw_part + (size_t)ceil_div(rows, NB_ROWS) * cols : nullptr;
+  const int nbr = nb_rows(rows);
+  float* dw_scratch = workspace ? dw_part + (size_t)ceil_div(rows, nbr) * cols : nullptr;
   int* dw_counters = workspace ? (int*)(dw_scratch + (size_t)DW_CHUNKS * cols) : nullptr;
   MR_CHECK_ARG(dxn && x1 && rstd && w && dx1, "add_rmsnorm_bwd: null pointer");
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
   DropCfg dy = make_drop(p_drop, seed, stream_y, step_dev), dn = make_drop(p_drop, seed, stream_out, step_dev);
 #define LAUNCH3(NV, TG, TRI, TRO)                                                                                 \
-  hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG, TRI, TRO>), dim3((unsigned)ceil_div(rows, NB_ROWS)), dim3(256), 0, \
+  hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG, TRI, TRO>), dim3((unsigned)ceil_div(rows, nbr)), dim3(256), 0, \
                      (hipStream_t)stream, (const TG*)dxn, (const TRI*)dres, x1, rstd, w, (TRO*)dx1, (bf16_t*)dy_bf16,  \
-                     dw_part, rows, cols, dy, dn, out_drop, dw_counters)
+                     dw_part, rows, cols, dy, dn, out_drop, dw_counters, nbr)
 #define LAUNCH2(NV, TG) LAUNCH3(NV, TG, float, float)
 #define LAUNCH(NV)                                       \
   do {                                                   \
@@ -359,7 +366,7 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
   MR_CHECK_LAUNCH("add_rmsnorm_bwd");
   if (dw) {
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)ceil_div(cols, 64), DW_CHUNKS), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)dw_part, dw, ceil_div(rows, NB_ROWS), cols, dw_scratch, dw_counters);
+                       (const float*)dw_part, dw, ceil_div(rows, nbr), cols, dw_scratch, dw_counters);
     MR_CHECK_LAUNCH("add_rmsnorm_bwd dw reduce");
   }
   return MRMT3_OK;

@@ -53,6 +53,8 @@ def worker(rank, mode, iters, port, graph):
                 out = fn(*a, **kw)
                 outs = out if isinstance(out, (tuple, list)) else (out,)
                 for j, o in enumerate(outs):
+                    if name in ("lmhead_cross_entropy", "cross_entropy") and j == 0:
+                        continue               # the logged loss: the one float-atomic sum of the step (order-dependent last bits)
                     if isinstance(o, torch.Tensor) and o.is_cuda:
                         log.append(("%s[%d] %s" % (name, j, tuple(o.shape)), bits(o)))
                 return out

@@ -336,7 +336,10 @@ def _attn_ref(q, k, v, B, H, Lq, Lk, causal):
 
 ATTN_SHAPES = [(2, 6, 256, 256, False), (2, 6, 1024, 1024, True), (1, 6, 1024, 320, False),
                (2, 3, 200, 72, False), (1, 2, 300, 300, True), (1, 6, 64, 1024, False), (1, 1, 1088, 1088, True),
-               (1, 1, 1, 1, False), (1, 2, 129, 257, False), (1, 1, 33, 33, True), (1, 2, 2048, 2112, False)]
+               (1, 1, 1, 1, False), (1, 2, 129, 257, False), (1, 1, 33, 33, True), (1, 2, 2048, 2112, False),
+               # enough (batch, head) pairs for the PAIRED causal instantiations (>= 512 tile pairs; smaller causal
+               # launches run their tiles unpaired), with an odd number of 128-row tiles
+               (22, 6, 1024, 1024, True), (36, 6, 640, 640, True)]
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", ATTN_SHAPES)
@@ -873,7 +876,10 @@ def test_gemm_tn_deferred_batch_is_bitwise_the_immediate_form(dev):
     (65536, 1536, 512, "f32", False), (16384, 512, 768, "f32", True),
     (4096 + 200, 1152, 512, "bf16", False),      # ragged M (zero-filled rows, masked stores) + half-overlapping last column tile
     (8192, 384, 128, "bf16", False),             # two K steps per tile: first, second and last K step coincide
-    (4096, 768, 256, "f32", False)])
+    (4096, 768, 256, "f32", False),
+    # 12 segments per GPU (the reference's own batch): 12288 decoder rows, 3072 encoder rows, less than one wave of tiles
+    (3072, 512, 1024, "bf16", False), (3072, 2048, 512, "bf16", False), (12288, 384, 512, "bf16", False),
+    (12288, 512, 1536, "f32", False), (2048 + 72, 512, 384, "bf16", False)])
 def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypatch, M, N, K, out, acc):
     """csrc/gemm8.hip (ping-pong phases, LDS-DMA two K steps ahead, epilogue spread over four phases with counted
     waits) on every admissible shape class: against an f32 torch product on ALL rows, and against gemm.hip's kernel
@@ -909,6 +915,31 @@ def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypa
     ref2 = wide_a[:, 128:].float() @ b.float().t()
     assert (wide_c[:, 256:].float() - ref2).abs().max().item() / ref2.abs().max().item() < (6e-3 if out == "bf16" else 2e-6)
     assert wide_c[:, :256].abs().max().item() == 0
+
+
+def test_gemm8_dispatch_rule_takes_whole_waves_of_tiles(dev, monkeypatch):
+    """Which NT shapes go to the ping-pong kernel by default (no tuning switches): at most one wave of workgroups, or a
+    last wave >= 80 % full; never the accumulate form.  (Cold A/B: profiles/r03_gemm_ab_*cold.txt.)"""
+    from mrmt3 import lib
+    monkeypatch.delenv("MRMT3_GEMM8_ALL", raising=False)
+    monkeypatch.delenv("MRMT3_GEMM8", raising=False)
+    monkeypatch.delenv("MRMT3_GEMM8_MIN_M", raising=False)
+    cases = [(65536, 1152, 512, True), (65536, 384, 512, True), (16384, 1152, 512, False), (12288, 512, 384, True),
+             (12288, 1024, 512, False), (12288, 1536, 512, False), (3072, 512, 2048, True), (3072, 1152, 512, True),
+             (1024, 512, 512, False), (65536, 512, 1024, True)]
+    for M, N, K, want in cases:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = torch.randn(N, K, device=dev).bfloat16()
+        before = lib.dispatch_counts()["gemm_nt8"]
+        c = lib.gemm_nt(a, b)
+        assert (lib.dispatch_counts()["gemm_nt8"] - before == 1) == want, (M, N, K, want)
+        rows = torch.randint(0, M, (64,), device=dev)
+        ref = a[rows].float() @ b.float().t()
+        assert (c[rows].float() - ref).abs().max().item() / ref.abs().max().item() < 6e-3
+    acc = torch.zeros(65536, 512, device=dev)
+    before = lib.dispatch_counts()["gemm_nt8"]
+    lib.gemm_nt(torch.randn(65536, 384, device=dev).bfloat16(), torch.randn(512, 384, device=dev).bfloat16(), out=acc, accumulate=True)
+    assert lib.dispatch_counts()["gemm_nt8"] == before
 
 
 def test_gemm8_and_tn8_race_screen_bitwise_repeatable_under_load(dev, monkeypatch):
