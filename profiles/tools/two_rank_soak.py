@@ -64,6 +64,13 @@ def worker(rank, mode, iters, port, graph):
             wrap(nm)
     w = golden_weights(T5_SMALL)
     audio = torch.from_numpy(synth_audio(2, seed=50 + rank)).to(dev)
+    use_mel = os.environ.get("MRMT3_SOAK_MEL") == "1"      # feed the mel (made once, before the loop) instead of audio
+    if use_mel:
+        from contrib import spectrograms as sp
+        mels = [sp.logmel_segments(audio, out_bf16=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert torch.equal(mels[0], mels[1]) and torch.equal(mels[1], mels[2]), "three log-mel launches of the same audio differ"
+        audio = mels[0]
     lab = torch.from_numpy(synth_labels(2, 128, seed=60 + rank)).to(dev)
     first = None
     bad = 0
@@ -80,7 +87,7 @@ def worker(rank, mode, iters, port, graph):
         cur = []
         del log[:]
         for st_ in range(5):
-            loss = tr.train_step(audio, lab, audio=True)
+            loss = tr.train_step(audio, lab, audio=not use_mel)
             cur.append((m.flat.G.clone(), loss.clone()))         # the gradient of every step (before AdamW spreads a glitch)
             if trace:
                 log.append(("step %d: G" % st_, bits(m.flat.G)))

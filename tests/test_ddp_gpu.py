@@ -7,6 +7,14 @@ RCCL) against ONE process that sees both ranks' segments:
     over its own tokens, token counts equal), i.e. what the single process computes on the concatenated batch;
   * the side-stream weight gradients are joined before their bucket is exchanged (a missed join shows up as a
     mismatch here).
+
+The ranks are fed the log-mel INPUT, computed once in this (parent) process before they start, not raw audio: two
+processes sharing one GPU is a configuration of this file only, and round 3 found that under it the log-mel kernel — a
+plain LDS FFT — is occasionally computed wrongly when workgroups of the OTHER process's LDS-DMA + MFMA kernels share its
+CU (profiles/r03_two_process_soak.txt: reproduced with a 60-line stand-alone FFT; not gloo, not the side stream, not the
+hand-offs; a lone process is bitwise repeatable).  That was the "1 in 40" mismatch round 2 retried on; with the frontend
+out of the two-process region the comparisons below hold on the first try (100 soak repetitions: 0 differences).  The
+frontend inside the training step is covered single-process (test_train_graph_gpu.py, test_train_infer_gpu.py).
 """
 import os
 import socket
@@ -29,8 +37,12 @@ def _free_port():
 
 
 def _batch(rank, B=2):
+    """(log-mel [B, 256, 512] bf16 as a CPU tensor, labels): the mel is made here, in the calling process, on the GPU."""
+    from contrib import spectrograms as sp
     from mrmt3.synthetic import synth_audio, synth_labels
-    return (torch.from_numpy(synth_audio(B, seed=50 + rank)), torch.from_numpy(synth_labels(B, 128, seed=60 + rank)))
+    audio = torch.from_numpy(synth_audio(B, seed=50 + rank)).cuda()
+    mel = sp.logmel_segments(audio, out_bf16=True)
+    return mel.cpu(), torch.from_numpy(synth_labels(B, 128, seed=60 + rank))
 
 
 def _model(dev):
@@ -39,7 +51,7 @@ def _model(dev):
     return T5ForConditionalGeneration(dict(T5_SMALL, dropout_rate=0.0)).load_golden().to(dev)
 
 
-def _worker(rank, world, port, q, steps=1, graph=False):
+def _worker(rank, world, port, q, batch, steps=1, graph=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "mr-mt3_amd")):
@@ -56,9 +68,9 @@ def _worker(rank, world, port, q, steps=1, graph=False):
             with torch.no_grad():
                 m.flat.P.mul_(1.5)                       # the trainer's initial broadcast must undo this
         tr = Trainer(m, lr=1e-3, graph=graph)
-        audio, lab = _batch(rank)
+        mel, lab = batch
         for _ in range(steps):
-            loss = tr.train_step(audio.to(dev), lab.to(dev), audio=True)
+            loss = tr.train_step(mel.to(dev), lab.to(dev), audio=False)
         torch.cuda.synchronize()
         assert tr.graph_captured == (graph and steps > 2)
         if tr.graph_captured:       # one graph per gradient bucket, the collectives stay eager between the replays
@@ -73,7 +85,9 @@ def _run_two_ranks(steps=1, graph=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, steps, graph)) for r in range(2)]
+    batches = [_batch(r) for r in range(2)]          # log-mel computed here, before the ranks share the GPU
+    torch.cuda.synchronize()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, batches[r], steps, graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
@@ -94,16 +108,7 @@ def test_two_ranks_segmented_graph_replay_equals_eager():
                    for (r0, g0, p0, l0), (r1, g1, p1, l1) in zip(a, b))
     eager = _run_two_ranks(steps=5, graph=False)
     graph = _run_two_ranks(steps=5, graph=True)
-    if not same(eager, graph):
-        # Two processes time-slicing ONE GPU (a configuration that exists only in this test) have been seen to make
-        # two identical EAGER runs differ in a few gradient elements about once in forty runs; a lone
-        # process is bitwise repeatable (test_train_graph_gpu.py, test_checkpoint_resume_...).  Tell the two apart:
-        # a real graph/eager difference repeats.
-        import warnings
-        warnings.warn("two-rank eager and graph runs differed once; repeating both")
-        eager = _run_two_ranks(steps=5, graph=False)
-        graph = _run_two_ranks(steps=5, graph=True)
-    assert same(eager, graph)
+    assert same(eager, graph)                  # on the first try (round 2 retried here: see the module docstring)
     assert np.array_equal(graph[0][2], graph[1][2])
 
 
@@ -120,7 +125,7 @@ def test_two_ranks_match_one_process_on_the_global_batch():
     tr = Trainer(m, lr=1e-3, graph=False)
     a0, t0 = _batch(0)
     a1, t1 = _batch(1)
-    loss = tr.train_step(torch.cat([a0, a1]).to(dev), torch.cat([t0, t1]).to(dev), audio=True)
+    loss = tr.train_step(torch.cat([a0, a1]).to(dev), torch.cat([t0, t1]).to(dev), audio=False)
     torch.cuda.synchronize()
     g = m.flat.G.cpu().numpy()
     # reduced gradient = sum over ranks; the trainer folds 1/world into AdamW's grad_scale
@@ -131,7 +136,7 @@ def test_two_ranks_match_one_process_on_the_global_batch():
     assert dp < 2.5e-3, dp                                          # one AdamW step of lr 1e-3 moves a weight by <= ~1e-3
 
 
-def _dropin_worker(rank, world, port, q):
+def _dropin_worker(rank, world, port, q, batch):
     """The reference's own training step shape (tasks/mt3_net.py: logits = model(...); CE; loss.backward()) under a
     multi-rank process group and WITHOUT mrmt3.trainer.Trainer."""
     import sys
@@ -149,8 +154,8 @@ def _dropin_worker(rank, world, port, q):
         if rank == 1:
             with torch.no_grad():
                 m.flat.P.mul_(1.5)                       # the first forward must start from rank 0's weights
-        audio, lab = _batch(rank)
-        mel = sp.logmel_segments(audio.to(dev)).float()
+        mel, lab = batch
+        mel = mel.to(dev).float()
         out = m(inputs=mel, labels=lab.to(dev))
         loss = torch.nn.functional.cross_entropy(out.view(-1, out.shape[-1]), lab.to(dev).view(-1), ignore_index=-100)
         loss.backward()
@@ -169,7 +174,9 @@ def test_dropin_backward_under_a_process_group_averages_the_gradients_itself():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dropin_worker, args=(r, 2, port, q)) for r in range(2)]
+    batches = [_batch(r) for r in range(2)]
+    torch.cuda.synchronize()
+    procs = [ctx.Process(target=_dropin_worker, args=(r, 2, port, q, batches[r])) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
@@ -184,8 +191,8 @@ def test_dropin_backward_under_a_process_group_averages_the_gradients_itself():
     gs = []
     for r in range(2):
         m = _model(dev).train()
-        audio, lab = _batch(r)
-        mel = sp.logmel_segments(audio.to(dev)).float()
+        mel, lab = batches[r]
+        mel = mel.to(dev).float()
         out = m(inputs=mel, labels=lab.to(dev))
         torch.nn.functional.cross_entropy(out.view(-1, out.shape[-1]), lab.to(dev).view(-1), ignore_index=-100).backward()
         gs.append(m.flat.G.clone())
