@@ -73,6 +73,10 @@ class Engine:
         self._side = None
         self._side_dirty = False
         self._held = []
+        # bf16(O - bf16(O)) of an attention site is kept for the backward's delta where the value rows share a large common
+        # component — cross-attention over near-identical encoder frames.  "all": every site; "cross": the
+        # self-attention sites skip the extra 50 MB write + read per site
+        self.lo_sites = os.environ.get("MRMT3_ATTN_LO", "all")
         self.norm_dw = lib.NormDwBatch() if os.environ.get("MRMT3_NORM_DW_BATCH", "1") != "0" else None
         # split-K slabs of the weight-gradient GEMMs: kept per site and summed in one launch (lib.TnBatch)
         self.tn_batch = lib.TnBatch() if os.environ.get("MRMT3_TN_BATCH", "1") != "0" else None
@@ -215,7 +219,7 @@ class Engine:
             s_att = self._sid()
             o, lse, o_lo = lib.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, L, L,
                                         is_decoder, p=p, seed=self.seed, step=self.step_dev, stream_id=s_att,
-                                        want_lse=keep, want_lo=keep)
+                                        want_lse=keep, want_lo=keep and self.lo_sites == "all")
             y = lib.gemm_nt(o, self.W(f"{prefix}.{i}.o"), out_dtype=self.y_dtype)
             sy = self._sid()
             if keep:
