@@ -1,0 +1,64 @@
+"""Host logic of mr-mt3_amd/train.py that needs no GPU: the data loaders under several ranks (what Lightning's DDP
+strategy does to the reference's plain DataLoaders, config/config.yaml:45) and the resume arithmetic of the batch
+iterator."""
+import sys
+
+import torch
+
+
+def _cfg(tmp_path, n_train=10, n_val=4):
+    from mrmt3 import hydra_lite
+    (tmp_path / "toyset2.py").write_text(
+        "import torch\n"
+        "from torch.utils.data import Dataset\n"
+        "class Toy(Dataset):\n"
+        "    def __init__(self, n): self.n = n\n"
+        "    def __len__(self): return self.n\n"
+        "    def __getitem__(self, i): return torch.full((1, 4), float(i)), torch.full((1, 2), i, dtype=torch.int64)\n"
+        "def collate(batch):\n"
+        "    return torch.cat([b[0] for b in batch]), torch.cat([b[1] for b in batch])\n")
+    if str(tmp_path) not in sys.path:
+        sys.path.insert(0, str(tmp_path))
+    return hydra_lite._wrap({
+        "seed": 365,
+        "dataset": {"train": {"_target_": "toyset2.Toy", "n": n_train}, "val": {"_target_": "toyset2.Toy", "n": n_val},
+                    "collate_fn": "toyset2.collate"},
+        "dataloader": {"train": {"batch_size": 2, "shuffle": True}, "val": {"batch_size": 2, "shuffle": False}}})
+
+
+def test_real_loaders_shard_the_datasets_over_the_ranks(tmp_path):
+    import train
+    cfg = _cfg(tmp_path)
+    tl, vl, sampler = train.real_loaders(cfg)                     # one rank: plain loaders, no sampler
+    assert sampler is None and sum(b[0].shape[0] for b in tl) == 10
+    seen, val_seen = [], []
+    for rank in range(2):
+        tl, vl, sampler = train.real_loaders(cfg, world=2, rank=rank)
+        assert sampler is not None
+        sampler.set_epoch(0)
+        seen.append(sorted(int(v) for b in tl for v in b[1][:, 0]))
+        val_seen.append(sorted(int(v) for b in vl for v in b[1][:, 0]))
+    # every rank gets half of the samples, together they cover the set exactly once (10 is divisible by 2: no padding)
+    assert len(seen[0]) == len(seen[1]) == 5 and sorted(seen[0] + seen[1]) == list(range(10))
+    assert sorted(val_seen[0] + val_seen[1]) == list(range(4))
+    # another epoch, another shuffle — the same one on both ranks (still a partition)
+    orders = []
+    for rank in range(2):
+        tl, _, sampler = train.real_loaders(cfg, world=2, rank=rank)
+        sampler.set_epoch(1)
+        orders.append([int(v) for b in tl for v in b[1][:, 0]])
+    assert sorted(orders[0] + orders[1]) == list(range(10))
+
+
+def test_loader_batches_counts_global_steps_and_resumes_mid_run(tmp_path):
+    import train
+    cfg = _cfg(tmp_path, n_train=6)
+    tl, _, _ = train.real_loaders(cfg)                            # 3 batches per epoch
+    dev = torch.device("cpu")
+    full = [(ep, int(x[0, 0])) for ep, x, _, _ in train.loader_batches(tl, dev, epochs=2, max_steps=None)]
+    assert [e for e, _ in full] == [0, 0, 0, 1, 1, 1]
+    capped = list(train.loader_batches(tl, dev, epochs=2, max_steps=4))
+    assert len(capped) == 4
+    # resumed at global step 3 in epoch 1 with max_steps = 5: two more steps, all in epoch 1
+    resumed = list(train.loader_batches(tl, dev, epochs=2, max_steps=5, start_epoch=1, start_step=3))
+    assert [b[0] for b in resumed] == [1, 1]
