@@ -268,6 +268,11 @@ def inference_rtf(dev, tokens, batch):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 while the bench
+    # runs (RCCL prints a five-line version banner there when its first communicator is created) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -421,7 +426,8 @@ def main():
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     sync()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1 or force_coll:
         dist.destroy_process_group()
 

@@ -224,6 +224,30 @@ def test_fp32_trainer_step_matches_torch_adamw_on_the_oracle(dev):
     print("fp32 trainer: worst rel-L2 of the three-step update vs torch.optim.AdamW on the oracle: %.2e" % worst)
 
 
+def test_fp32_training_with_dropout_draws_the_bf16_masks_and_replays_from_graphs(dev):
+    """The fp32 engine with dropout ON: (i) it draws the masks of the bf16 engine (same seed, site ids and step counter), so
+    its loss trajectory stays within bf16 noise of the bf16 engine's — a different mask anywhere moves the loss by ~5e-2;
+    (ii) the step replayed from hipGraphs equals the eager step bit for bit, like the bf16 path."""
+    from mrmt3.synthetic import T5_SMALL, synth_mel, synth_labels
+    from mrmt3.trainer import Trainer
+    from models.t5 import T5ForConditionalGeneration
+    mel = torch.from_numpy(synth_mel(2, seed=8)).to(dev)
+    lab = torch.from_numpy(synth_labels(2, 128, full=False, seed=9, mean_len=80)).to(dev)
+    runs = {}
+    for name, dtype, graph in (("bf16", torch.bfloat16, False), ("f32", torch.float32, False), ("f32_graph", torch.float32, True)):
+        m = T5ForConditionalGeneration(T5_SMALL, compute_dtype=dtype).load_golden().to(dev)
+        tr = Trainer(m, lr=1e-3, graph=graph)
+        losses = [tr.train_step(mel if dtype == torch.float32 else mel.bfloat16(), lab).item() for _ in range(5)]
+        torch.cuda.synchronize()
+        assert tr.graph_captured == graph
+        runs[name] = (losses, m.flat.P.clone())
+    assert all(np.isfinite(runs[k][0]).all() for k in runs)
+    assert np.allclose(runs["f32"][0], runs["bf16"][0], atol=8e-3), (runs["f32"][0], runs["bf16"][0])
+    assert runs["f32"][0][-1] < runs["f32"][0][1]                       # it trains (step 0 is before the first update)
+    assert np.allclose(runs["f32"][0], runs["f32_graph"][0], rtol=0, atol=2e-6)
+    assert torch.equal(runs["f32"][1], runs["f32_graph"][1])
+
+
 def test_lightning_style_steps_of_the_segment_memory_tasks(dev):
     """MT3NetSegMemV2WithPrev (3-tuple batches, cosine schedule) and its FineTune subclass (bare AdamW) driven the way
     Lightning drives them: training_step -> backward -> optimizer step, validation_step under no_grad."""
