@@ -76,6 +76,7 @@ def roofline_pass(trainer, audio, labels, prev, steps):
     """Instrumented repeat of the timed steps: events around every heavy launch on the launch stream."""
     from mrmt3 import lib
     lib.PROFILE = []
+    lib.PROFILE_BYTES.clear()
     for _ in range(steps):
         trainer.train_step(audio, labels, prev, audio=True)
     torch.cuda.synchronize()
@@ -378,17 +379,21 @@ def main():
 
         f = fam[dom]
         # HBM traffic of the dominant family: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction
-        # of MI355X_MICROARCH.md) cannot run inside this process; the per-shape table they produced for this tree is
-        # committed (profiles/r02_pmc_gemm_traffic.json, made by profiles/tools/pmc_traffic.sh) and folded in here
-        # per launch: sum over the step's launches of the measured bytes / number of launches.
+        # of MI355X_MICROARCH.md) cannot run inside this process; the whole-step table they produced for this tree is
+        # committed (profiles/r03_pmc_step_traffic.json, made by profiles/tools/pmc_step_traffic.sh) and folded in here.
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")) as fh:
-                tab = json.load(fh)
-            traffic = {"bytes_per_launch": tab["nt_bytes_per_step"] / tab["nt_launches_per_step"],
-                       "algorithmic_bytes_per_launch": tab["nt_algorithmic_bytes_per_step"] / tab["nt_launches_per_step"],
-                       "ratio": tab["nt_bytes_per_step"] / tab["nt_algorithmic_bytes_per_step"],
-                       "source": "profiles/r02_pmc_gemm_traffic.json"}
+            # measured: the family's row of the whole-step PMC table (profiles/r03_pmc_step_traffic.json: 2 x FETCH_SIZE +
+            # WRITE_SIZE over one eager step, separate passes); algorithmic: operands once + output once, summed over
+            # this run's launches of the family
+            from mrmt3 import lib as _lib
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json")) as fh:
+                fam_tab = json.load(fh)["families"]["gemm_nt"]
+            meas = (fam_tab["read_bytes"] + fam_tab["write_bytes"]) / fam_tab["launches"]
+            alg = _lib.PROFILE_BYTES.get(dom, 0.0) / max(f["n"], 1)
+            traffic = {"bytes_per_launch": meas, "algorithmic_bytes_per_launch": alg, "ratio": meas / alg if alg else None,
+                       "source": "profiles/r03_pmc_step_traffic.json (B = 64 table: %d launches of the family per step incl. "
+                                 "the lm_head chunks launched inside mrmt3_lmhead_ce_fwd_bwd)" % fam_tab["launches"]}
         except Exception:
             pass
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": rate(f), "peak": PEAK_BF16_TFLOPS,

@@ -127,6 +127,7 @@ def dispatch_counts(reset: bool = False) -> dict:
 # the heavy kernels bracket their launch with events on the current stream and append
 # (family, algorithmic_work, unit, start_event, end_event).
 PROFILE = None
+PROFILE_BYTES = {}      # family -> algorithmic bytes (operands read once + output written once) while PROFILE is on
 
 
 class _Timed:
@@ -222,7 +223,10 @@ def gemm_nt(a, b, out=None, out_dtype=None, accumulate=False):
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
     assert out.stride(1) == 1
-    with _Timed("gemm_nt_bf16" if a.dtype == torch.bfloat16 else "gemm_nt_f32", 2.0 * M * N * K, "FLOP"):
+    fam = "gemm_nt_bf16" if a.dtype == torch.bfloat16 else "gemm_nt_f32"
+    if PROFILE is not None:
+        PROFILE_BYTES[fam] = PROFILE_BYTES.get(fam, 0.0) + (M * K + N * K) * a.element_size() + M * N * out.element_size()
+    with _Timed(fam, 2.0 * M * N * K, "FLOP"):
         _check(load().mrmt3_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _dt(a),
                                     _dt(out), int(accumulate), _stream()), "gemm_nt")
     return out

@@ -170,6 +170,7 @@ __device__ __forceinline__ c2 twiddle(const c2* tw, int idx) {
   if (idx & 1024) { t.x = -t.x; t.y = -t.y; }
   return t;
 }
+template <int VAR>
 __global__ __launch_bounds__(256) void fft_canary(const float* __restrict__ in_g, const float* __restrict__ twid, float* __restrict__ ref,
                                                   int make_ref, unsigned* n_bad, Rec* recs, int max_recs) {
   __shared__ __attribute__((aligned(16))) c2 buf0[1024];
@@ -187,10 +188,14 @@ __global__ __launch_bounds__(256) void fft_canary(const float* __restrict__ in_g
     const int k = tid & (p - 1);
     const int j = ((tid - k) << 2) + k;
     const int twm = (512 >> (2 * pass)) * k;
+    // VAR 1: no twiddle multiplies (adds / subtracts only); VAR 2: twiddles applied but read ONCE before the loop from
+    // the global table (no LDS table); VAR 3: the first two passes only; VAR 4: multiplies by a constant instead
+    if (VAR == 3 && pass >= 2) break;
     c2 u0 = in[tid];
-    c2 u1 = cmul(in[tid + t], twiddle(tw, twm));
-    c2 u2 = cmul(in[tid + 2 * t], twiddle(tw, 2 * twm));
-    c2 u3 = cmul(in[tid + 3 * t], twiddle(tw, 3 * twm));
+    c2 u1 = in[tid + t], u2 = in[tid + 2 * t], u3 = in[tid + 3 * t];
+    if (VAR == 0 || VAR == 3) { u1 = cmul(u1, twiddle(tw, twm)); u2 = cmul(u2, twiddle(tw, 2 * twm)); u3 = cmul(u3, twiddle(tw, 3 * twm)); }
+    if (VAR == 2) { u1 = cmul(u1, ((const c2*)twid)[twm & 1023]); u2 = cmul(u2, ((const c2*)twid)[(2 * twm) & 1023]); u3 = cmul(u3, ((const c2*)twid)[(3 * twm) & 1023]); }
+    if (VAR == 4) { const c2 k1 = {0.7071f, -0.7071f}; u1 = cmul(u1, k1); u2 = cmul(u2, k1); u3 = cmul(u3, k1); }
     c2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3);
     c2 d = csub(u1, u3);
     c2 v3 = {d.y, -d.x};
@@ -211,11 +216,17 @@ __global__ __launch_bounds__(256) void fft_canary(const float* __restrict__ in_g
   }
 }
 
+#define FFT_LAUNCH(G, MK) do { switch (var) { case 1: hipLaunchKernelGGL(fft_canary<1>, dim3(G), dim3(256), 0, 0, in_g, tw_g, ref_g, MK, n_bad, recs, max_recs); break; \
+      case 3: hipLaunchKernelGGL(fft_canary<3>, dim3(G), dim3(256), 0, 0, in_g, tw_g, ref_g, MK, n_bad, recs, max_recs); break; \
+      case 4: hipLaunchKernelGGL(fft_canary<4>, dim3(G), dim3(256), 0, 0, in_g, tw_g, ref_g, MK, n_bad, recs, max_recs); break; \
+      default: hipLaunchKernelGGL(fft_canary<0>, dim3(G), dim3(256), 0, 0, in_g, tw_g, ref_g, MK, n_bad, recs, max_recs); } } while (0)
+
 int main(int argc, char** argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 10.0;
   const int kib = argc > 2 ? atoi(argv[2]) : 24;
   const int spin = argc > 3 ? atoi(argv[3]) : 40;
   const int mode = argc > 4 ? atoi(argv[4]) : 0;
+  const int var = argc > 5 ? atoi(argv[5]) : 0;
   const unsigned words = kib * 256;
   unsigned* n_bad; Rec* recs; const int max_recs = 4096;
   hipMalloc(&n_bad, 4); hipMalloc(&recs, sizeof(Rec) * max_recs);
@@ -229,13 +240,13 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 1024; ++i) { ht[2 * i] = (float)cos(-2 * M_PI * i / 2048); ht[2 * i + 1] = (float)sin(-2 * M_PI * i / 2048); }
     hipMalloc(&in_g, 8192); hipMalloc(&tw_g, 8192); hipMalloc(&ref_g, 8192);
     hipMemcpy(in_g, h, 8192, hipMemcpyHostToDevice); hipMemcpy(tw_g, ht, 8192, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(fft_canary, dim3(1), dim3(256), 0, 0, in_g, tw_g, ref_g, 1, n_bad, recs, max_recs);
+    FFT_LAUNCH(1, 1);
     hipDeviceSynchronize();
     // the reference itself may have been taken beside the aggressor: take it three times and insist they agree
     float r1[2048], r2[2048];
     hipMemcpy(r1, ref_g, 8192, hipMemcpyDeviceToHost);
     for (int k = 0; k < 2; ++k) {
-      hipLaunchKernelGGL(fft_canary, dim3(1), dim3(256), 0, 0, in_g, tw_g, ref_g, 1, n_bad, recs, max_recs);
+      FFT_LAUNCH(1, 1);
       hipDeviceSynchronize();
       hipMemcpy(r2, ref_g, 8192, hipMemcpyDeviceToHost);
       if (memcmp(r1, r2, 8192)) printf("fft canary: two reference launches already differ\n");
@@ -269,7 +280,7 @@ int main(int argc, char** argv) {
       else if (mode == 5) { hipLaunchKernelGGL(twiddle_canary, dim3(512), dim3(256), 0, 0, iter, n_bad, recs, max_recs); iter++; }
       else if (mode == 4) { hipLaunchKernelGGL(move_canary, dim3(512), dim3(256), 0, 0, iter, n_bad, recs, max_recs); iter++; }
       else if (mode == 3) { hipLaunchKernelGGL(load_canary, dim3(512), dim3(256), 0, 0, tab_g, n_bad, recs, max_recs); iter++; }
-      else if (mode == 2) { hipLaunchKernelGGL(fft_canary, dim3(512), dim3(256), 0, 0, in_g, tw_g, ref_g, 0, n_bad, recs, max_recs); iter++; }
+      else if (mode == 2) { FFT_LAUNCH(512, 0); iter++; }
       else if (mode == 1) hipLaunchKernelGGL(exchange, dim3(512), dim3(256), 0, 0, iter++, n_bad, recs, max_recs);
       else hipLaunchKernelGGL(canary, dim3(512), dim3(256), kib * 1024, 0, words, iter++, n_bad, recs, max_recs, spin);
     }
@@ -280,7 +291,7 @@ int main(int argc, char** argv) {
   else if (mode == 5) printf("twiddle canary: %u launches of 512 workgroups, %u threads read a wrong table word\n", iter, nb);
   else if (mode == 4) printf("move canary: %u launches of 512 workgroups x 5 passes, %u threads read a wrong word\n", iter, nb);
   else if (mode == 3) printf("load canary: %u launches of 512 workgroups x 2048 words, %u wrong words (wg 0x1000|n: straight from the global load; 0x2000|n: after LDS)\n", iter, nb);
-  else if (mode == 2) printf("fft canary: %u launches of 512 workgroups, %u output words differ from the reference\n", iter, nb);
+  else if (mode == 2) printf("fft canary (variant %d): %u launches of 512 workgroups, %u output words differ from the reference\n", var, iter, nb);
   else if (mode == 1) printf("exchange: %u launches of 512 workgroups x 64 barrier rounds, %u threads read a stale or foreign word\n", iter, nb);
   else printf("canary: %u launches of 512 workgroups x %d KiB LDS, %u corrupted words\n", iter, kib, nb);
   if (nb) {

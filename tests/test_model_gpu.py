@@ -242,7 +242,10 @@ def test_fp32_training_with_dropout_draws_the_bf16_masks_and_replays_from_graphs
         assert tr.graph_captured == graph
         runs[name] = (losses, m.flat.P.clone())
     assert all(np.isfinite(runs[k][0]).all() for k in runs)
-    assert np.allclose(runs["f32"][0], runs["bf16"][0], atol=8e-3), (runs["f32"][0], runs["bf16"][0])
+    # same masks: the first steps agree to bf16 noise (measured 6e-4 .. 3e-3; another mask anywhere moves a loss by ~5e-2);
+    # later steps drift apart as the bf16 rounding of three updates at lr 1e-3 accumulates (1.3e-2 at step 4)
+    d = np.abs(np.array(runs["f32"][0]) - np.array(runs["bf16"][0]))
+    assert d[:3].max() < 5e-3 and d.max() < 3e-2, (runs["f32"][0], runs["bf16"][0])
     assert runs["f32"][0][-1] < runs["f32"][0][1]                       # it trains (step 0 is before the first update)
     assert np.allclose(runs["f32"][0], runs["f32_graph"][0], rtol=0, atol=2e-6)
     assert torch.equal(runs["f32"][1], runs["f32_graph"][1])
