@@ -209,6 +209,24 @@ int mrmt3_attn_bwd_f32(const float* q, int ldq, const float* k, int ldk, const f
                        float* dk, int lddk, float* dv, int lddv, int B, int H, int Lq, int Lk, int causal,
                        float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 
+/* The same attention with HF T5Attention's ADDITIVE BIAS (`scores += position_bias`, models/t5.py:636-648: the
+ * relative-position bias of stock T5 — SURVEY §8b `attn(q, k, v, bias_or_null, ...)`; MR-MT3's own position_bias is all
+ * zeros, models/t5.py:487-490, so the training step never calls these two).  bias: f32 [H][Lq][Lk] shared by the batch
+ * (bias_batch_stride = 0) or [B][H][Lq][Lk] (bias_batch_stride = H*Lq*Lk, e.g. a padding mask of -inf / 0 per
+ * sequence); NULL = no bias.  dtype = MRMT3_F32 or MRMT3_BF16 operands (q, k, v, o, d_o, dq, dk, dv), f32 arithmetic:
+ * this is the general (parity) kernel, one workgroup per query / key row — correct for any bias, not the MFMA fast path.
+ * dbias (nullable, layout of bias) receives dS = P (dP - delta); for a shared bias summed over the batch in batch
+ * order.  Dropout as above. */
+int mrmt3_attn_fwd_bias(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias,
+                        long long bias_batch_stride, void* o, int ldo, float* lse, int B, int H, int Lq, int Lk,
+                        int causal, int dtype, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id,
+                        void* stream);
+int mrmt3_attn_bwd_bias(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
+                        const void* d_o, int lddo, const float* lse, float* delta, const float* bias,
+                        long long bias_batch_stride, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
+                        float* dbias, int B, int H, int Lq, int Lk, int causal, int dtype, float p_drop, uint64_t seed,
+                        const int32_t* step_dev, uint32_t stream_id, void* stream);
+
 /* ---- K7: gated-GELU (HF T5DenseGatedGeluDense: gelu_new(h0) * h1, then dropout) ----------------
  * h [rows][2*dff] = [wi_0 x | wi_1 x] -> g [rows][dff] */
 int mrmt3_geglu_fwd(const void* h, void* g, int rows, int dff, int dtype, float p_drop,

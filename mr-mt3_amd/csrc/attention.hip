@@ -553,209 +553,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
   }  // pass
 }
 
-// ------------------------------------------------------------------------------------------------
-// exact-f32 attention (parity path): one workgroup per (query, head, batch)
-// ------------------------------------------------------------------------------------------------
-// element (q, key) of head-matrix bh kept?  (the generator of the bf16 kernels, one element at a time)
-__device__ __forceinline__ bool attn_keep1(const AttnDrop& d, unsigned drop_bh, int q, int key) {
-  const unsigned w = mix24(drop_bh + (unsigned)q * DROP_CQ + ((unsigned)key >> 2) * DROP_CK);
-  return ((w >> (8 * (key & 3))) & 0xFFu) >= d.thresh8;
-}
-
-__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
-                                                       int ldk, const float* __restrict__ v, int ldv,
-                                                       float* __restrict__ o, int ldo, float* __restrict__ lse, int H,
-                                                       int Lq, int Lk, int causal, AttnDrop drop) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // scores[Lk] | q[64] | red[8] | part[4][64]
-  float* sc = sm;
-  float* qs = sm + Lk;
-  float* red = qs + 64;
-  float* part = red + 8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const float* qp = q + ((size_t)b * Lq + qi) * ldq + h * HD;
-  const float* kb = k + (size_t)b * Lk * ldk + h * HD;
-  const float* vb = v + (size_t)b * Lk * ldv + h * HD;
-  if (tid < 64) qs[tid] = qp[tid];
-  __syncthreads();
-  const int nk = causal ? min(Lk, qi + 1) : Lk;
-  float mx = -INFINITY;
-  for (int key = tid; key < nk; key += 256) {
-    const float* kr = kb + (size_t)key * ldk;
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      f32x4 kv = *(const f32x4*)(kr + d);
-      s = fmaf(qs[d], kv.x, s); s = fmaf(qs[d + 1], kv.y, s); s = fmaf(qs[d + 2], kv.z, s); s = fmaf(qs[d + 3], kv.w, s);
-    }
-    sc[key] = s;
-    mx = fmaxf(mx, s);
-  }
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float se = 0.f;
-  for (int key = tid; key < nk; key += 256) {
-    const float p = expf(sc[key] - mx);
-    sc[key] = p;
-    se += p;
-  }
-  se = wave_sum(se);
-  if (lane == 0) red[4 + wave] = se;
-  __syncthreads();
-  se = red[4] + red[5] + red[6] + red[7];
-  if (drop.thresh8) {      // the normaliser is the sum of ALL probabilities; dropped ones leave the product only
-    const unsigned drop_bh = drop.seed + step_salt(drop.step) + (unsigned)(b * H + h) * DROP_CB;
-    for (int key = tid; key < nk; key += 256)
-      if (!attn_keep1(drop, drop_bh, qi, key)) sc[key] = 0.f;
-    __syncthreads();
-  }
-  float acc = 0.f;
-  for (int key = wave; key < nk; key += 4) acc = fmaf(sc[key], vb[(size_t)key * ldv + lane], acc);
-  part[wave * 64 + lane] = acc;
-  __syncthreads();
-  if (tid < 64) {
-    const float r = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-    o[((size_t)b * Lq + qi) * ldo + h * HD + tid] = r * drop.scale / se;
-  }
-  if (tid == 0 && lse) lse[((size_t)b * H + h) * Lq + qi] = mx + logf(se);
-}
-
-// exact-f32 backward of the same (the reference trains in fp32, config/config_slakh_segmem.yaml:47 `precision: 32`):
-// (1) one workgroup per query row: delta = rowsum(dO * O), dS = P (keep * scale * dP - delta), dQ = dS . K;
-// (2) one workgroup per key row: dV = Pd^T dO, dK = dS^T Q.  Every sum runs in a fixed order (no atomics).
-__global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
-                                                              int ldk, const float* __restrict__ v, int ldv,
-                                                              const float* __restrict__ o, int ldo,
-                                                              const float* __restrict__ d_o, int lddo,
-                                                              const float* __restrict__ lse, float* __restrict__ delta,
-                                                              float* __restrict__ dq, int lddq, int H, int Lq, int Lk,
-                                                              int causal, AttnDrop drop) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // ds[Lk] | q[64] | dO[64] | red[4] | part[4][64]
-  float* sc = sm;
-  float* qs = sm + Lk;
-  float* dos = qs + 64;
-  float* red = dos + 64;
-  float* part = red + 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const size_t qrow = (size_t)b * Lq + qi;
-  const float* kb = k + (size_t)b * Lk * ldk + h * HD;
-  const float* vb = v + (size_t)b * Lk * ldv + h * HD;
-  const unsigned drop_bh = drop.seed + step_salt(drop.step) + (unsigned)(b * H + h) * DROP_CB;
-  if (tid < 64) {
-    qs[tid] = q[qrow * ldq + h * HD + tid];
-    dos[tid] = d_o[qrow * lddo + h * HD + tid];
-  }
-  __syncthreads();
-  float dl = 0.f;
-  if (wave == 0) {
-    dl = wave_sum(dos[lane] * o[qrow * ldo + h * HD + lane]);
-    if (lane == 0) { red[0] = dl; delta[((size_t)b * H + h) * Lq + qi] = dl; }
-  }
-  __syncthreads();
-  dl = red[0];
-  const float l = lse[((size_t)b * H + h) * Lq + qi];
-  const int nk = causal ? min(Lk, qi + 1) : Lk;
-  for (int key = tid; key < nk; key += 256) {
-    const float* kr = kb + (size_t)key * ldk;
-    const float* vr = vb + (size_t)key * ldv;
-    float sv = 0.f, dp = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      const f32x4 kv = *(const f32x4*)(kr + d), vv = *(const f32x4*)(vr + d);
-      sv = fmaf(qs[d], kv.x, sv); sv = fmaf(qs[d + 1], kv.y, sv); sv = fmaf(qs[d + 2], kv.z, sv); sv = fmaf(qs[d + 3], kv.w, sv);
-      dp = fmaf(dos[d], vv.x, dp); dp = fmaf(dos[d + 1], vv.y, dp); dp = fmaf(dos[d + 2], vv.z, dp); dp = fmaf(dos[d + 3], vv.w, dp);
-    }
-    const float pr = expf(sv - l);
-    if (drop.thresh8) dp = attn_keep1(drop, drop_bh, qi, key) ? dp * drop.scale : 0.f;
-    sc[key] = pr * (dp - dl);
-  }
-  __syncthreads();
-  float acc = 0.f;
-  for (int key = wave; key < nk; key += 4) acc = fmaf(sc[key], kb[(size_t)key * ldk + lane], acc);
-  part[wave * 64 + lane] = acc;
-  __syncthreads();
-  if (tid < 64) dq[qrow * lddq + h * HD + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-}
-
-__global__ __launch_bounds__(256) void attn_f32_bwd_dkdv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
-                                                                int ldk, const float* __restrict__ v, int ldv,
-                                                                const float* __restrict__ d_o, int lddo,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dk, int lddk, float* __restrict__ dv,
-                                                                int lddv, int H, int Lq, int Lk, int causal, AttnDrop drop) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // pd[Lq] | ds[Lq] | k[64] | v[64] | part[2][4][64]
-  float* pd = sm;
-  float* ds = sm + Lq;
-  float* ks = ds + Lq;
-  float* vs = ks + 64;
-  float* part = vs + 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int key = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const size_t krow = (size_t)b * Lk + key;
-  const float* qb = q + (size_t)b * Lq * ldq + h * HD;
-  const float* dob = d_o + (size_t)b * Lq * lddo + h * HD;
-  const float* lseb = lse + ((size_t)b * H + h) * Lq;
-  const float* dltb = delta + ((size_t)b * H + h) * Lq;
-  const unsigned drop_bh = drop.seed + step_salt(drop.step) + (unsigned)(b * H + h) * DROP_CB;
-  if (tid < 64) {
-    ks[tid] = k[krow * ldk + h * HD + tid];
-    vs[tid] = v[krow * ldv + h * HD + tid];
-  }
-  __syncthreads();
-  const int q_lo = causal ? key : 0;
-  for (int qi = q_lo + tid; qi < Lq; qi += 256) {
-    const float* qr = qb + (size_t)qi * ldq;
-    const float* dr = dob + (size_t)qi * lddo;
-    float sv = 0.f, dp = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      const f32x4 qv = *(const f32x4*)(qr + d), dv4 = *(const f32x4*)(dr + d);
-      sv = fmaf(qv.x, ks[d], sv); sv = fmaf(qv.y, ks[d + 1], sv); sv = fmaf(qv.z, ks[d + 2], sv); sv = fmaf(qv.w, ks[d + 3], sv);
-      dp = fmaf(dv4.x, vs[d], dp); dp = fmaf(dv4.y, vs[d + 1], dp); dp = fmaf(dv4.z, vs[d + 2], dp); dp = fmaf(dv4.w, vs[d + 3], dp);
-    }
-    float pr = expf(sv - lseb[qi]);
-    float keep = 1.f;
-    if (drop.thresh8) keep = attn_keep1(drop, drop_bh, qi, key) ? drop.scale : 0.f;
-    pd[qi] = pr * keep;
-    ds[qi] = pr * (dp * keep - dltb[qi]);
-  }
-  __syncthreads();
-  float av = 0.f, ak = 0.f;
-  for (int qi = q_lo + wave; qi < Lq; qi += 4) {
-    av = fmaf(pd[qi], dob[(size_t)qi * lddo + lane], av);
-    ak = fmaf(ds[qi], qb[(size_t)qi * ldq + lane], ak);
-  }
-  part[wave * 64 + lane] = av;
-  part[256 + wave * 64 + lane] = ak;
-  __syncthreads();
-  if (tid < 64) {
-    dv[krow * lddv + h * HD + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-    dk[krow * lddk + h * HD + tid] = (part[256 + tid] + part[320 + tid]) + (part[384 + tid] + part[448 + tid]);
-  }
-}
-
+// exact-f32 attention (the reference's `precision: 32`) lives in attention_general.hip: one workgroup per query / key row,
+// f32 arithmetic, the same masks; these two entry points launch it without a bias.
 extern "C" int mrmt3_attn_bwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                                   int ldo, const float* d_o, int lddo, const float* lse, float* delta, float* dq, int lddq,
                                   float* dk, int lddk, float* dv, int lddv, int B, int H, int Lq, int Lk, int causal,
                                   float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_bwd_f32: null pointer");
   MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_bwd_f32: bad sizes");
-  MR_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && lddo % 4 == 0, "attn_bwd_f32: strides must be multiples of 4");
-  const size_t shm_q = (size_t)(Lk + 64 + 64 + 4 + 256) * sizeof(float), shm_k = (size_t)(2 * Lq + 128 + 512) * sizeof(float);
-  MR_CHECK_ARG(shm_q <= 160 * 1024 && shm_k <= 160 * 1024, "attn_bwd_f32: sequence too long for the parity kernel");
-  const AttnDrop drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_f32_bwd_dq_kernel, dim3(Lq, H, B), dim3(256), shm_q, s, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo,
-                     lse, delta, dq, lddq, H, Lq, Lk, causal, drop);
-  MR_CHECK_LAUNCH("attn_bwd_f32 dq");
-  hipLaunchKernelGGL(attn_f32_bwd_dkdv_kernel, dim3(Lk, H, B), dim3(256), shm_k, s, q, ldq, k, ldk, v, ldv, d_o, lddo, lse,
-                     delta, dk, lddk, dv, lddv, H, Lq, Lk, causal, drop);
-  MR_CHECK_LAUNCH("attn_bwd_f32 dkdv");
-  mrmt3_count(MRMT3_CNT_ATTN_F32);
-  return MRMT3_OK;
+  return mrmt3_attn_general_bwd(q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, nullptr, 0, dq, lddq, dk, lddk, dv,
+                                lddv, nullptr, B, H, Lq, Lk, causal, MRMT3_F32,
+                                make_attn_drop(p_drop, seed, stream_id, step_dev), (hipStream_t)stream);
 }
 
 extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
@@ -764,17 +572,9 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   MR_CHECK_ARG(q && k && v && o, "attn_fwd: null pointer");
   MR_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_fwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MRMT3_F32) {
-    MR_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "attn_fwd: f32 strides must be multiples of 4");
-    const size_t shm = (size_t)(Lk + 64 + 8 + 256) * sizeof(float);
-    MR_CHECK_ARG(shm <= 160 * 1024, "attn_fwd f32: Lk too large");
-    hipLaunchKernelGGL(attn_f32_kernel, dim3(Lq, H, B), dim3(256), shm, s, (const float*)q, ldq, (const float*)k, ldk,
-                       (const float*)v, ldv, (float*)o, ldo, lse, H, Lq, Lk, causal,
-                       make_attn_drop(p_drop, seed, stream_id, step_dev));
-    MR_CHECK_LAUNCH("attn_fwd f32");
-    mrmt3_count(MRMT3_CNT_ATTN_F32);
-    return MRMT3_OK;
-  }
+  if (dtype == MRMT3_F32)
+    return mrmt3_attn_general_fwd(q, ldq, k, ldk, v, ldv, nullptr, 0, o, ldo, lse, B, H, Lq, Lk, causal, MRMT3_F32,
+                                  make_attn_drop(p_drop, seed, stream_id, step_dev), s);
   MR_CHECK_ARG(dtype == MRMT3_BF16, "attn_fwd: unknown dtype");
   MR_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attn_fwd: bf16 strides must be multiples of 8");
   AttnParams P;

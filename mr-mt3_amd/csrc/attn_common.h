@@ -160,3 +160,12 @@ __device__ __forceinline__ void blds_rows8(__amdgpu_buffer_rsrc_t r, unsigned la
 
 // attention_onepass.hip: the backward in one pass when a workgroup can own all keys of a (batch, head); 1 = launched
 int mrmt3_attn_bwd_onepass_try(const AttnParams& P, hipStream_t s);
+
+// attention_general.hip: exact-f32 arithmetic on f32 / bf16 operands, optional additive bias and its gradient
+int mrmt3_attn_general_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias,
+                           long long bias_bs, void* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int causal,
+                           int dtype, const AttnDrop& drop, hipStream_t s);
+int mrmt3_attn_general_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
+                           const void* d_o, int lddo, const float* lse, float* delta, const float* bias, long long bias_bs,
+                           void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, float* dbias, int B, int H, int Lq,
+                           int Lk, int causal, int dtype, const AttnDrop& drop, hipStream_t s);

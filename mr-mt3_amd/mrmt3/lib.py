@@ -53,6 +53,10 @@ _SIGS = {
     "mrmt3_gemm_tn_f32": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]),
     "mrmt3_attn_bwd_f32": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci,
                                 cf, cu64, vp, cu32, vp]),
+    "mrmt3_attn_fwd_bias": (ci, [vp, ci, vp, ci, vp, ci, vp, C.c_longlong, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, cu64, vp,
+                                 cu32, vp]),
+    "mrmt3_attn_bwd_bias": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, C.c_longlong, vp, ci, vp, ci, vp, ci, vp,
+                                 ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_embed_bwd_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_embed_bwd": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp, csz, vp]),
@@ -593,6 +597,43 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, causal, p=0.0, seed
                                      dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, int(causal), p, seed,
                                      _p(step), stream_id, _stream()), "attn_bwd")
     return dq, dk, dv
+
+
+def _bias_stride(bias, B, H, Lq, Lk):
+    assert bias.dtype == torch.float32 and bias.is_contiguous()
+    if tuple(bias.shape) == (H, Lq, Lk):
+        return 0
+    assert tuple(bias.shape) == (B, H, Lq, Lk), "bias is [H, Lq, Lk] (shared by the batch) or [B, H, Lq, Lk]"
+    return H * Lq * Lk
+
+
+def attn_fwd_bias(q, k, v, bias, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, step=None):
+    """softmax(q k^T + bias [+ causal]) v — HF T5Attention with its additive position bias (models/t5.py:636-648).  The
+    general kernel (f32 arithmetic on f32 / bf16 operands), not the MFMA path: MR-MT3's own bias is zero and its step
+    calls attn_fwd.  Returns (o, lse)."""
+    _dev(q, k, v, bias)
+    o = torch.empty(B * Lq, H * 64, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    bs = 0 if bias is None else _bias_stride(bias, B, H, Lq, Lk)
+    _check(load().mrmt3_attn_fwd_bias(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(bias), bs, _p(o),
+                                      o.stride(0), _p(lse), B, H, Lq, Lk, int(causal), _dt(q), p, seed, _p(step), stream_id,
+                                      _stream()), "attn_fwd_bias")
+    return o, lse
+
+
+def attn_bwd_bias(q, k, v, o, d_o, lse, bias, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, step=None, want_dbias=True):
+    """Backward of attn_fwd_bias: returns (dq, dk, dv, dbias); dbias has the bias's shape (summed over the batch when the
+    bias is shared) or is None."""
+    _dev(q, k, v, o, d_o, lse, bias)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    bs = 0 if bias is None else _bias_stride(bias, B, H, Lq, Lk)
+    dbias = torch.empty_like(bias) if (want_dbias and bias is not None) else None
+    _check(load().mrmt3_attn_bwd_bias(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                      _p(d_o), d_o.stride(0), _p(lse), _p(delta), _p(bias), bs, _p(dq), dq.stride(0), _p(dk),
+                                      dk.stride(0), _p(dv), dv.stride(0), _p(dbias), B, H, Lq, Lk, int(causal), _dt(q), p,
+                                      seed, _p(step), stream_id, _stream()), "attn_bwd_bias")
+    return dq, dk, dv, dbias
 
 
 def geglu_fwd(h, p=0.0, seed=0, stream_id=0, step=None):

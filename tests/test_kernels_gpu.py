@@ -593,6 +593,95 @@ def test_attn_f32_dropout_is_the_bf16_kernels_mask_and_consistent_forward_to_bac
     assert np.abs(dv.view(B, Lk, H, 64)[..., 0].permute(0, 2, 1).cpu().numpy() - want).max() < 1e-5
 
 
+def _t5_relative_bias(H, Lq, Lk, dev, seed=5):
+    """A stock-T5 style position bias [H, Lq, Lk]: a learned table indexed by the bucketed relative position (what HF
+    T5Attention.compute_bias builds; MR-MT3 replaces it by zeros, models/t5.py:487-490).  Returns (table, buckets)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    table = torch.randn(32, H, generator=g).to(dev).requires_grad_(True)
+    rel = torch.arange(Lk)[None, :] - torch.arange(Lq)[:, None]
+    buckets = (rel.clamp(-15, 16) + 15).to(dev)                               # 32 buckets
+    return table, buckets
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Lq,Lk,causal,shared", [(2, 6, 128, 128, True, True), (3, 2, 100, 320, False, True),
+                                                     (2, 3, 64, 72, False, False), (1, 1, 1, 1, False, True)])
+def test_attn_with_additive_bias_matches_autograd_including_the_bias_gradient(dev, dt, B, H, Lq, Lk, causal, shared):
+    """mrmt3_attn_fwd_bias / mrmt3_attn_bwd_bias (SURVEY §8b `attn(q, k, v, bias_or_null)`, HF T5Attention's
+    `scores += position_bias`, models/t5.py:636-648) against torch autograd in f32: a relative-position bias shared by the
+    batch (its gradient sums over the batch and flows on into the bucket table) and a per-sequence bias that also
+    masks padded keys with -inf."""
+    from mrmt3 import lib
+    q = (torch.randn(B * Lq, H * 64, device=dev) * 0.35).to(dt).requires_grad_(True)
+    k = torch.randn(B * Lk, H * 64, device=dev).to(dt).requires_grad_(True)
+    v = torch.randn(B * Lk, H * 64, device=dev).to(dt).requires_grad_(True)
+    d_o = torch.randn(B * Lq, H * 64, device=dev).to(dt)
+    table, buckets = _t5_relative_bias(H, Lq, Lk, dev)
+    if shared:
+        bias = table[buckets].permute(2, 0, 1).contiguous()                    # [H, Lq, Lk]
+        full = bias[None]
+    else:
+        pad = torch.zeros(B, 1, 1, Lk, device=dev)
+        for b in range(B):
+            pad[b, ..., Lk - 5 * (b + 1):] = float("-inf")                     # the last keys of sequence b are padding
+        bias = (table[buckets].permute(2, 0, 1)[None] + pad).contiguous()      # [B, H, Lq, Lk]
+        full = bias
+    bias.retain_grad()
+    qh = q.float().view(B, Lq, H, 64).transpose(1, 2)
+    kh = k.float().view(B, Lk, H, 64).transpose(1, 2)
+    vh = v.float().view(B, Lk, H, 64).transpose(1, 2)
+    sc = qh @ kh.transpose(2, 3) + full
+    if causal:
+        i = torch.arange(Lq, device=dev)[:, None]
+        j = torch.arange(Lk, device=dev)[None, :]
+        sc = sc.masked_fill(j > i, float("-inf"))
+    oref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B * Lq, H * 64)
+    lref = torch.logsumexp(sc, -1)
+    oref.backward(d_o.float())
+
+    bd = bias.detach()
+    o, lse = lib.attn_fwd_bias(q.detach(), k.detach(), v.detach(), bd, B, H, Lq, Lk, causal)
+    tol = 2e-5 if dt == torch.float32 else 6e-3
+    assert o.dtype == dt and _rel(o, oref) < tol and torch.allclose(lse, lref, atol=1e-5 if dt == torch.float32 else 1e-4)
+    dq, dk, dv, dbias = lib.attn_bwd_bias(q.detach(), k.detach(), v.detach(), o, d_o, lse, bd, B, H, Lq, Lk, causal)
+    for got, ref, name in ((dq, q.grad, "dq"), (dk, k.grad, "dk"), (dv, v.grad, "dv"), (dbias, bias.grad, "dbias")):
+        # (one key: dS = P (dP - delta) is exactly 0 in autograd and rounding noise here — absolute bound)
+        assert got.shape == ref.shape and (_rel(got, ref) < 2 * tol or (got.float() - ref).abs().max() < 1e-5), (name, _rel(got, ref))
+    if causal:
+        assert (dbias[:, 0, 1:] == 0).all()                                    # masked keys get a zero, not garbage
+    # the bias gradient flows on into the learned table exactly as autograd's does
+    tg = torch.zeros_like(table).index_put_((buckets.reshape(-1),),
+                                            (dbias if shared else dbias.sum(0)).permute(1, 2, 0).reshape(-1, H), accumulate=True)
+    assert _rel(tg, table.grad) < 2 * tol or (tg - table.grad).abs().max() < 1e-5
+    # no bias at all == the bias-free entry points, bit for bit (f32: same kernel; bf16: general kernel vs MFMA kernel, close)
+    o0, l0 = lib.attn_fwd_bias(q.detach(), k.detach(), v.detach(), None, B, H, Lq, Lk, causal)
+    o1, l1 = lib.attn_fwd(q.detach(), k.detach(), v.detach(), B, H, Lq, Lk, causal)
+    if dt == torch.float32:
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    else:
+        assert _rel(o0, o1) < 1e-2
+
+
+def test_attn_bias_dropout_draws_the_same_mask_and_rejects_a_bad_bias(dev):
+    from mrmt3 import lib
+    from oracle import dropout_ref as dr
+    B, H, Lq, Lk, p, seed, stream = 2, 2, 48, 64, 0.1, 77, 3
+    q = torch.zeros(B * Lq, H * 64, device=dev)
+    k = torch.zeros(B * Lk, H * 64, device=dev)
+    v = torch.eye(64, device=dev).repeat(B, H)
+    bias = torch.zeros(H, Lq, Lk, device=dev)
+    o, lse = lib.attn_fwd_bias(q, k, v, bias, B, H, Lq, Lk, False, p=p, seed=seed, stream_id=stream)
+    keep, scale = dr.attn_keep_mask(B, H, Lq, Lk, p, seed, stream)
+    got = o.view(B, Lq, H, 64).permute(0, 2, 1, 3).cpu().numpy()
+    assert ((got != 0) == keep).all() and abs(got.max() - scale / Lk) < 1e-6
+    with pytest.raises(AssertionError):
+        lib.attn_fwd_bias(q, k, v, torch.zeros(H, Lq, Lk + 1, device=dev), B, H, Lq, Lk, False)
+    L = lib.load()
+    rc = L.mrmt3_attn_fwd_bias(lib._p(q), q.stride(0), lib._p(k), k.stride(0), lib._p(v), v.stride(0), lib._p(bias), 17,
+                               lib._p(o), o.stride(0), lib._p(lse), B, H, Lq, Lk, 0, 0, 0.0, 0, None, 0, lib._stream())
+    assert rc != 0 and b"bias batch stride" in L.mrmt3_last_error()
+
+
 @pytest.mark.parametrize("M,N1,N2", [(512, 512, 384), (1000, 384, 512), (130, 1536, 512), (64, 70, 36)])
 def test_gemm_tn_f32(dev, M, N1, N2):
     from mrmt3 import lib
