@@ -320,7 +320,11 @@ __global__ __launch_bounds__(256) void tn8_group_reduce_kernel(const T8RTile* __
 
 // Plan shared with gemm.hip's mrmt3_gemm_tn*: returns 1 when this kernel takes the shape.
 int mrmt3_tn8_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per_split) {
-  if (M < 8192 || N1 < 256 || N2 < 256 || N1 % 8 != 0 || N2 % 8 != 0) return 0;
+  // The shifted last tile (columns N - 256 .. N) is addressed in whole half-tiles of 128 features on the dY side and in
+  // 64-column fragments on the X side: N1 must be a multiple of 128 and N2 of 64 (the grouped launch's rule,
+  // mrmt3_tn_group_ok).  Other widths go to gemm_tn_kernel (found by tests/test_fuzz_gpu.py: N1 = 576 was admitted
+  // with % 8 and came back wrong in rows 512..575).
+  if (M < 8192 || N1 < 256 || N2 < 256 || N1 % 128 != 0 || N2 % 64 != 0) return 0;
   if ((size_t)M * (size_t)(N1 > N2 ? N1 : N2) * 2 >= 0x7FFF0000ull) return 0;
   static int cus = 0;
   if (cus == 0) {
