@@ -159,3 +159,118 @@ def test_mfma_attention_agrees_with_the_general_kernels_under_dropout(dev, B, H,
         assert _rel(got, ref) < tol or (got.float() - ref).abs().max() < 1e-4, (name, _rel(got, ref), c)
     if Lk == 256 and not causal and B * H >= 96:
         assert c["attn_bwd_onepass"] == 1, c
+
+
+# ---- row-wise kernels at row counts nobody chose ------------------------------------------------------------------------
+ROWS = [1, 3, 31, 33, 257, 1000, 2047, 2049, 3072, 12289, 16384, 40001]
+
+
+def _gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
+
+
+@pytest.mark.parametrize("rows", ROWS)
+@pytest.mark.parametrize("cols,ydt,rdt", [(512, torch.bfloat16, torch.bfloat16), (512, torch.float32, torch.float32),
+                                          (256, torch.bfloat16, torch.float32), (1024, torch.float32, torch.float32),
+                                          (2048, torch.bfloat16, torch.float32)])
+def test_add_rmsnorm_random_rows(dev, rows, cols, ydt, rdt):
+    """x1 = x0 + y, xn = RMSNorm(x1) w and its backward (incl. the norm-weight gradient's partial rows) at every row count,
+    both residual-gradient stream types, against autograd in f32."""
+    from mrmt3 import lib
+    if rows > 20000 and cols > 512:
+        pytest.skip("large case only at the model width")
+    g = torch.Generator(device="cpu").manual_seed(rows * 13 + cols)
+    x0 = torch.randn(rows, cols, generator=g).to(dev)
+    y = torch.randn(rows, cols, generator=g).to(dev).to(ydt)
+    w = (1 + 0.1 * torch.randn(cols, generator=g)).to(dev)
+    x1, xn, rstd = lib.add_rmsnorm_fwd(x0, y, w, 1e-6, torch.bfloat16)
+    x1r = (x0 + y.float()).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    xnr = wr * (x1r * torch.rsqrt(x1r.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert torch.allclose(x1, x1r, atol=1e-6) and _rel(xn, xnr) < 4e-3
+    assert torch.allclose(rstd, torch.rsqrt(x1r.detach().pow(2).mean(-1) + 1e-6), rtol=1e-5, atol=1e-7)
+    dxn = torch.randn(rows, cols, generator=g).to(dev).bfloat16()
+    dres = torch.randn(rows, cols, generator=g).to(dev).to(rdt)
+    (xnr * dxn.float()).sum().backward()
+    dw = torch.zeros(cols, device=dev)
+    dx1, dy = lib.add_rmsnorm_bwd(dxn, dres, x1, rstd, w, dw, dx1_dtype=rdt)
+    want = x1r.grad + dres.float()
+    assert _rel(dx1, want) < (4e-3 if rdt == torch.bfloat16 else 1e-5)
+    assert _rel(dy, want) < 4e-3
+    assert _rel(dw, wr.grad) < 2e-5, _rel(dw, wr.grad)
+
+
+@pytest.mark.parametrize("rows", ROWS)
+@pytest.mark.parametrize("dff", [1024, 8, 200, 1536])
+def test_geglu_random_rows_and_widths(dev, rows, dff):
+    from mrmt3 import lib
+    if rows > 20000 and dff != 1024:
+        pytest.skip("large case only at the model width")
+    g = torch.Generator(device="cpu").manual_seed(rows + dff)
+    hb = torch.randn(rows, 2 * dff, generator=g).to(dev).bfloat16()
+    hr = hb.float().requires_grad_(True)
+    gr = _gelu_new(hr[:, :dff]) * hr[:, dff:]
+    gb = lib.geglu_fwd(hb)
+    assert _rel(gb, gr) < 4e-3
+    dg = torch.randn(rows, dff, generator=g).to(dev).bfloat16()
+    (gr * dg.float()).sum().backward()
+    assert _rel(lib.geglu_bwd(hb, dg), hr.grad) < 4e-3
+    # dropout: forward and backward draw the same mask, kept elements scaled by 1 / (1 - p)
+    gd = lib.geglu_fwd(hb, p=0.1, seed=7, stream_id=3)
+    kept = gd != 0
+    frac = kept.float().mean().item()
+    if rows * dff > 20000:
+        assert abs(frac - 0.9) < 0.02, frac
+    big = gb.float().abs() > 1e-2
+    assert torch.allclose(gd.float()[kept & big], (gb.float() / 0.9)[kept & big], rtol=1.2e-2)
+    dhd = lib.geglu_bwd(hb, dg, p=0.1, seed=7, stream_id=3)
+    dropped_rows_cols = (~kept) & big
+    assert (dhd[:, :dff][dropped_rows_cols] == 0).all() and (dhd[:, dff:][dropped_rows_cols] == 0).all()
+
+
+@pytest.mark.parametrize("rows,dff,K", [(4096, 1024, 512), (4097, 1024, 512), (12288, 1024, 512), (2048, 512, 256),
+                                        (20001, 1024, 512), (5000, 384, 128), (3000, 1024, 512), (1, 1024, 512)])
+def test_fused_wi_geglu_random_shapes_equal_the_two_kernels(dev, rows, dff, K):
+    """mrmt3_gemm_nt_geglu (projection + gated GELU + dropout in one launch, or its unfused fallback for shapes the
+    ping-pong kernel does not take) against gemm_nt followed by geglu_fwd: the same bits, dropout on."""
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(rows + dff + K)
+    x = torch.randn(rows, K, generator=g).to(dev).bfloat16()
+    wi = (torch.randn(2 * dff, K, generator=g) * 0.05).to(dev).bfloat16()
+    h, gg = lib.gemm_nt_geglu(x, wi, p=0.1, seed=11, stream_id=2)
+    h2 = lib.gemm_nt(x, wi)
+    g2 = lib.geglu_fwd(h2, p=0.1, seed=11, stream_id=2)
+    assert torch.equal(h, h2) and torch.equal(gg, g2)
+    ref = x.float() @ wi.float().t()
+    assert _rel(h, ref) < 4e-3
+
+
+@pytest.mark.parametrize("rows,V,chunk", [(1, 1536, 16384), (1000, 1536, 256), (2049, 1536, 2048), (16385, 1536, 16384),
+                                          (40001, 1536, 16384), (777, 512, 100), (3000, 2048, 1024)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_lmhead_ce_random_rows_vocabularies_and_chunks(dev, rows, V, chunk, weighted):
+    """lm_head + cross entropy over row chunks against torch: loss (mean over non-ignored rows, or the reference's
+    instrument-weighted form), dlogits, ragged last chunk, ignore_index rows."""
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(rows + V)
+    dec = torch.randn(rows, 512, generator=g).to(dev).bfloat16()
+    w = (torch.randn(V, 512, generator=g) * 0.05).to(dev).bfloat16()
+    tg = torch.randint(0, V, (rows,), generator=g).to(dev)
+    tg[::5] = -100
+    if rows == 1:
+        tg[0] = 3
+    inst_lo, inst_hi = V // 2, V // 2 + 100
+    loss, dl = lib.lmhead_cross_entropy(dec, w, tg, grad_dtype=torch.float32, weighted=weighted, inst_lo=inst_lo,
+                                        inst_hi=inst_hi, chunk_rows=chunk)
+    logits = (dec.float() @ w.float().t()).double().requires_grad_(True)
+    valid = tg != -100
+    per_row = torch.nn.functional.cross_entropy(logits, tg.clamp(min=0), reduction="none")
+    if weighted:
+        # the reference's weighted loss (tasks/mt3_net.py:75-165) as restated — and pinned — in oracle/t5_ref.py
+        from oracle import t5_ref
+        ref = t5_ref.weighted_ce_loss(logits[None], tg[None], lo=inst_lo, hi=inst_hi)
+    else:
+        ref = (per_row * valid).sum() / valid.sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    assert torch.allclose(dl.double(), logits.grad, atol=1e-7, rtol=2e-4)
