@@ -274,3 +274,66 @@ def test_lmhead_ce_random_rows_vocabularies_and_chunks(dev, rows, V, chunk, weig
     ref.backward()
     assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
     assert torch.allclose(dl.double(), logits.grad, atol=1e-7, rtol=2e-4)
+
+
+# ---- the whole model at shapes nobody chose -------------------------------------------------------------------------------
+def _build(variant, dtype, dev):
+    from mrmt3.synthetic import T5_SMALL
+    if variant == "t5":
+        from models.t5 import T5ForConditionalGeneration as M
+        m = M(T5_SMALL, compute_dtype=dtype)
+    else:
+        import importlib
+        mod, cls = {"segmem_v1": ("models.t5_segmem", "T5SegMem"), "segmem_v2": ("models.t5_segmem_v2", "T5SegMemV2"),
+                    "segmem_v2_with_prev": ("models.t5_segmem_v2_with_prev", "T5SegMemV2WithPrev")}[variant]
+        m = getattr(importlib.import_module(mod), cls)(T5_SMALL, segmem_num_layers=1, segmem_length=64,
+                                                       compute_dtype=dtype)
+    return m.load_golden().to(dev).eval()
+
+
+@pytest.mark.parametrize("variant,B,frames,Ld", [("t5", 3, 256, 72), ("segmem_v2_with_prev", 1, 200, 200),
+                                                 ("segmem_v1", 5, 256, 104), ("segmem_v2", 3, 136, 136),
+                                                 ("t5", 7, 64, 8), ("segmem_v2_with_prev", 4, 256, 328)])
+def test_model_gradients_at_odd_batch_sizes_and_lengths_match_the_oracle(dev, variant, B, frames, Ld):
+    """Odd batch sizes, encoder lengths off the 256-frame grid and target lengths off every tile size: the fp32 engine
+    (exact-f32 kernels) against oracle/t5_ref.py autograd to rel-L2 1e-4 per gradient tensor, and the bf16 engine
+    (MFMA kernels) to bf16 noise (cosine > 0.999, rel-L2 < 6e-2; loss within 1e-3 + 2e-2 / sqrt(valid tokens))."""
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel, synth_labels
+    from oracle import t5_ref
+    torch.set_num_threads(8)
+    mel = torch.from_numpy(synth_mel(B, frames=frames, seed=B + frames))
+    lab = torch.from_numpy(synth_labels(B, Ld, full=False, seed=70 + Ld, mean_len=max(2, Ld // 2)))
+    prev = torch.from_numpy(synth_labels(B, Ld, full=False, seed=90 + Ld, mean_len=max(2, Ld // 2)))
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in golden_weights(T5_SMALL, 0 if variant == "t5" else 1).items()}
+    logits = t5_ref.forward_logits(sd, T5_SMALL, mel, lab, variant=variant, targets_prev=prev.clone())
+    ref_loss = t5_ref.ce_loss(logits, lab)
+    ref_loss.backward()
+    for dt in (torch.float32, torch.bfloat16):
+        m = _build(variant, dt, dev)
+        out = m(inputs=mel.to(dev), labels=lab.to(dev), targets_prev=prev.clone().to(dev))
+        assert out.shape == logits.shape
+        loss = torch.nn.functional.cross_entropy(out.float().view(-1, 1536), lab.to(dev).view(-1), ignore_index=-100)
+        m.flat.ensure_grads()
+        m.flat.G.zero_()
+        loss.backward()
+        # bf16: north_star's 1e-3 is stated for a full batch (65 536 target tokens); the mean over the n valid tokens of
+        # these small cases carries the per-token logit noise (<= 3e-2, test_model_gpu.py) divided by sqrt(n)
+        n_valid = int((lab != -100).sum())
+        tol = 2e-5 if dt == torch.float32 else 1e-3 + 2e-2 / n_valid ** 0.5
+        assert abs(loss.item() - ref_loss.item()) < tol, (dt, loss.item(), ref_loss.item(), n_valid)
+        worst = (0.0, "")
+        for k, ref in sd.items():
+            g = m.flat.grad(k).float().cpu()
+            r = ref.grad
+            if r is None or r.norm() == 0:
+                assert g.norm() < 1e-6, k
+                continue
+            rel = ((g - r).norm() / r.norm()).item()
+            worst = max(worst, (rel, k))
+            if dt == torch.float32:
+                assert rel < 1e-4, (k, rel)
+            else:
+                cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
+                assert cos > 0.999 and rel < 6e-2, (k, cos, rel)
+        print(variant, B, frames, Ld, dt, "worst rel-L2 %.3e (%s)" % worst)
+        del m
