@@ -337,3 +337,28 @@ def test_model_gradients_at_odd_batch_sizes_and_lengths_match_the_oracle(dev, va
                 assert cos > 0.999 and rel < 6e-2, (k, cos, rel)
         print(variant, B, frames, Ld, dt, "worst rel-L2 %.3e (%s)" % worst)
         del m
+
+
+@pytest.mark.parametrize("variant,B,frames,ml", [("t5", 5, 200, 37), ("t5", 11, 256, 21), ("segmem_v2_with_prev", 3, 136, 80),
+                                                 ("segmem_v2", 7, 72, 70), ("t5", 1, 8, 70)])
+def test_greedy_decode_at_odd_batches_and_encoder_lengths_is_the_oracles_token_ids(dev, variant, B, frames, ml):
+    """fp32 greedy decode (KV cache, hipGraph replay, early EOS) at batch sizes and encoder lengths off every tile against
+    the oracle's cache-free loop (models/t5.py:251-302 restated): the same token ids."""
+    from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel
+    from oracle import t5_ref
+    torch.set_num_threads(8)
+    w = golden_weights(T5_SMALL, 0 if variant == "t5" else 1)
+    w["lm_head.weight"] = w["lm_head.weight"].copy()
+    w["lm_head.weight"][1] *= 2.6          # EOS competitive: some rows finish early, others run to the end
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    mel = torch.from_numpy(synth_mel(B, frames=frames, seed=B * 7 + frames))
+    gen = {"t5": t5_ref.generate_t5,
+           "segmem_v2": lambda *a, **k: t5_ref.generate_segmem_v2(*a, with_prev=False, **k),
+           "segmem_v2_with_prev": lambda *a, **k: t5_ref.generate_segmem_v2(*a, with_prev=True, **k)}[variant]
+    with torch.no_grad():
+        ref = gen(sd, T5_SMALL, mel, max_length=ml)
+    m = _build(variant, torch.float32, dev)
+    with torch.no_grad():
+        m.flat.load_numpy(w)
+    ids = m.generate(mel.to(dev), max_length=ml)
+    assert torch.equal(ids.cpu(), ref), (ids.cpu(), ref)
