@@ -32,6 +32,11 @@
 #define KV_STAGES 3
 #define KV_STAGE_BYTES 16384   // K tile 8 KiB + V tile 8 KiB
 
+static int attn_tile_mode() {
+  const char* e = getenv("MRMT3_ATTN_TILE_MODE");      // tuning only
+  return e ? (int)strtol(e, nullptr, 0) : 5;
+}
+
 template <bool PAIR, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   int tile_, h, b;
-  attn_tile(tile_, h, b);
+  attn_tile(tile_, h, b, P.tile_mode);
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   int tile_, h, b;
-  attn_tile(tile_, h, b);
+  attn_tile(tile_, h, b, P.tile_mode);
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
   const int uw = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 15, fg = lane >> 4, fq = fr >> 2, fp = lane & 3;
   int tile_, h, b;
-  attn_tile(tile_, h, b);
+  attn_tile(tile_, h, b, P.tile_mode);
   const bf16_t* qb = P.q + (size_t)b * P.Lq * P.ldq + h * HD;
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
@@ -584,6 +589,7 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo;
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
+  P.tile_mode = attn_tile_mode();
   const bool pair = attn_paired(Lq, causal, H, B);
   const dim3 grid(attn_grid_x(Lq, pair), H, B);
   if (pair && P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, P);
@@ -612,6 +618,7 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.ldo = ldo; P.lddo = lddo; P.lddq = lddq; P.lddk = lddk; P.lddv = lddv;
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
+  P.tile_mode = attn_tile_mode();
   hipStream_t s = (hipStream_t)stream;
   if (mrmt3_attn_bwd_onepass_try(P, s)) {      // all keys of a (batch, head) in one workgroup: dQ, dK, dV in one pass
     MR_CHECK_LAUNCH("attn_bwd onepass");

@@ -100,6 +100,7 @@ struct AttnParams {
   float* delta;
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int B, H, Lq, Lk, causal;
+  int tile_mode;     // (tuning) attn_tile: low nibble = flip shift (0 = none), bit 4 = zigzag order inside a group
   AttnDrop drop;
 };
 
@@ -121,13 +122,24 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* tile, int row, in
 // of one (batch, head) stream the same K/V (or Q/dO) rows, so they are made to run on ONE XCD, back to back:
 // XCD x takes the contiguous range [x*n/8, (x+1)*n/8) of the (b, h, tile) space, tile fastest.  Without this the
 // 8 query tiles of a head land on 8 different XCDs and every one of them pulls K/V through the fabric again.
-__device__ __forceinline__ void attn_tile(int& tile, int& h, int& b) {
+__device__ __forceinline__ void attn_tile(int& tile, int& h, int& b, int mode) {
   const int nt = gridDim.x, H = gridDim.y;
   const int n = nt * H * (int)gridDim.z;
   int w = blockIdx.x + nt * (blockIdx.y + H * blockIdx.z);
   if ((n & 7) == 0) w = (w & 7) * (n >> 3) + (w >> 3);
   tile = w % nt;
   const int bh = w / nt;
+  // A small causal launch (12 segments: 576 unpaired workgroups for 768 slots) is resident all at once, and the
+  // dispatcher deals an XCD's workgroups over its 32 CUs in rounds: with tile = j % 8 a CU gets the SAME tile index in
+  // every round — 2-3 x 16 key tiles on some CUs, 2-3 x 2 on others.  Every other round of 32 (mode & 15 = 5) takes its
+  // tiles in descending order instead, so a CU's workgroups are (t, nt-1-t).  Measured on the decoder self-attention,
+  // forward / backward: 8 segments 35.8 -> 28.1 / 91.9 -> 76.8 us, 12 segments 47.5 -> 39.5 / 117.4 -> 106.4, 16
+  // segments 49.2 -> 41.2 / 135.4 -> 120.0; from 22 segments the tiles run paired (equal work) and nothing changes.
+  // Other round lengths (8, 16, 64) and a zigzag order inside a group were no better (MRMT3_ATTN_TILE_MODE, tuning).
+  // (whole (batch, head) groups flip — the position of the group's first tile in its XCD's share decides, a function of
+  // bh alone — so the map stays a bijection for any nt, H, B)
+  if (mode & 16) tile = (tile & 1) ? nt - 1 - (tile >> 1) : (tile >> 1);
+  if ((mode & 15) && ((((bh * nt) % ((n & 7) == 0 ? (n >> 3) : n)) >> (mode & 15)) & 1) != 0) tile = nt - 1 - tile;
   h = bh % H;
   b = bh / H;
 }

@@ -1,4 +1,5 @@
-"""Micro-benchmark of the attention shapes of the training step (batch 64), dropout off / on."""
+"""Micro-benchmark of the attention shapes of the training step, dropout off / on.
+Usage: python profiles/tools/attn_micro.py [reps = 10] [segments = 64]"""
 import os
 import sys
 
@@ -11,8 +12,9 @@ if os.environ.get("MRMT3_TOOL_LIB"):      # tuning tool only: A/B a variant buil
 
 dev = torch.device("cuda:0")
 lib.load()
-B, H = 64, 6
+H = 6
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 
 
 def timeit(fn):
