@@ -65,7 +65,8 @@ void mrmt3_host_free(void* p);
 #define MRMT3_CNT_ATTN_BWD_ONEPASS 8  /* bf16 one-pass backward (keys of a (batch, head) owned by one workgroup) */
 #define MRMT3_CNT_ATTN_F32 9          /* exact-f32 attention kernels */
 #define MRMT3_CNT_TN_F32 10           /* exact-f32 weight-gradient kernel */
-#define MRMT3_CNT_N 11
+#define MRMT3_CNT_GEMM_NT_SPLITK 11   /* ping-pong NT kernel split over K + reduce (mrmt3_gemm_nt_ws, short inputs) */
+#define MRMT3_CNT_N 12
 int mrmt3_dispatch_counts(unsigned long long* out, int n, int reset);
 
 /* ---- K1: log-mel frontend ---------------------------------------------------------------------
@@ -99,6 +100,14 @@ int mrmt3_logmel_crops_fwd(const float* audio, long long total_samples, const lo
  * Requirements: K*sizeof(in) % 128 == 0; lda/ldb/ldc are row strides in elements. */
 int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                   int K, int in_dtype, int out_dtype, int accumulate, void* stream);
+/* The same product with a caller-owned scratch buffer.  Short inputs with a long K (the encoder's 3072 rows at 12
+ * segments per GPU: 24-48 tiles for 256 CUs) are cut into 2-4 K ranges that run as tiles of ONE launch — f32 partial sums
+ * in the workspace — and are summed in split order by a second kernel (fixed order, no atomics; C bf16 or f32, += for the
+ * accumulate form).  mrmt3_gemm_nt_workspace_bytes returns what that takes for a shape, 0 when the shape does not split:
+ * then, and with workspace == NULL or too small, the call IS mrmt3_gemm_nt. */
+size_t mrmt3_gemm_nt_workspace_bytes(int M, int N, int K, int in_dtype);
+int mrmt3_gemm_nt_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     int in_dtype, int out_dtype, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* TN (weight gradient):  C[N1,N2] (+)= A[M,N1]^T . B[M,N2], bf16 inputs, f32 output, reduction over
  * the M rows split across workgroups; `workspace` must hold mrmt3_gemm_tn_workspace_bytes(...). */
 size_t mrmt3_gemm_tn_workspace_bytes(int M, int N1, int N2);

@@ -301,6 +301,28 @@ extern "C" int mrmt3_gemm_nt(const void* A, int lda, const void* B, int ldb, voi
   return MRMT3_ERR_INVALID_ARG;
 }
 
+int mrmt3_gemm_nt8_splitk_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                              int in_dtype, int out_dtype, int accumulate, void* workspace, size_t workspace_bytes,
+                              hipStream_t s);
+
+// mrmt3_gemm_nt with a caller-owned scratch buffer (mrmt3_gemm_nt_workspace_bytes): short inputs with a long K run
+// split over K (gemm8.hip); everything else — and a NULL / too small workspace — is mrmt3_gemm_nt itself.
+extern "C" int mrmt3_gemm_nt_ws(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                int in_dtype, int out_dtype, int accumulate, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (workspace && A && B && C && M > 0 && N > 0 && K > 0 && in_dtype == MRMT3_BF16 &&
+      (out_dtype == MRMT3_BF16 || out_dtype == MRMT3_F32) && !(accumulate && out_dtype != MRMT3_F32) &&
+      (lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && (ldc * (out_dtype == MRMT3_BF16 ? 2 : 4)) % 16 == 0 &&
+      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 && use_gemm8()) {
+    if (mrmt3_gemm_nt8_splitk_try(A, lda, B, ldb, C, ldc, M, N, K, in_dtype, out_dtype, accumulate, workspace,
+                                  workspace_bytes, (hipStream_t)stream)) {
+      MR_CHECK_LAUNCH("gemm_nt (split K)");
+      return MRMT3_OK;
+    }
+  }
+  return mrmt3_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, in_dtype, out_dtype, accumulate, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // TN: C[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (bf16 in, f32 out)
 // ------------------------------------------------------------------------------------------------

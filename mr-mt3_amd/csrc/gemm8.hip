@@ -53,6 +53,10 @@ struct G8Params {
   void* C2;
   int ldc2, dff;
   DropCfg drop;
+  // split K (short inputs: too few tiles for the chip and a long K): `ksplit` partial products, each over `K` (the
+  // per-split depth) of `kfull` columns, written as f32 to a slab [ksplit][mpad][N] (C = the slab, ldc = N); row tile
+  // indices run over ksplit * mpad VIRTUAL rows.  ksplit = 1: kfull = K, mpad unused.
+  int ksplit, mpad, kfull;
   int dbg;             // diagnostics (MRMT3_GEMM8_DBG): 1 no C stores, 2 plain instead of streaming C stores (bf16), 4 every K step re-reads K step 0 (cache-hot),
                        // 8 no fragment reads, 16 loads switched off (zero fill, no traffic)
   int skew_ticks;      // start delay per (slot % 8), in 10-ns ticks of s_memrealtime (see the kernel)
@@ -131,8 +135,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     cmin = nt * 256;                                        // columns below belong to the tile on the left
   };
 
-  const __amdgpu_buffer_rsrc_t ra = g8_rsrc(P.A, ((size_t)(P.M - 1) * P.lda + P.K) * 2);
-  const __amdgpu_buffer_rsrc_t rb = g8_rsrc(P.B, ((size_t)(P.N - 1) * P.ldb + P.K) * 2);
+  // split K (f32, non-accumulating instantiations only: the others compile exactly as before): tile rows are virtual,
+  // row block z = m0 / mpad is K range [z * K, (z + 1) * K) of the operands and slab z of the output
+  constexpr bool SPLITK = sizeof(TOUT) == 4 && !ACCUM && EPI == 0;
+  auto src_off = [&](int m0, int n0, int& sa, int& sb) {
+    if constexpr (SPLITK) {
+      if (P.ksplit > 1) {
+        const int z = m0 / P.mpad;
+        sa = (m0 - z * P.mpad) * P.lda * 2 + z * P.K * 2;
+        sb = n0 * P.ldb * 2 + z * P.K * 2;
+        return;
+      }
+    }
+    sa = m0 * P.lda * 2;
+    sb = n0 * P.ldb * 2;
+  };
+  auto row_limit = [&](int m0) -> int {                       // first row index past the rows a tile at m0 may store
+    if constexpr (SPLITK) {
+      if (P.ksplit > 1) return (m0 / P.mpad) * P.mpad + P.M;
+    }
+    return P.M;
+  };
+  const __amdgpu_buffer_rsrc_t ra = g8_rsrc(P.A, ((size_t)(P.M - 1) * P.lda + P.kfull) * 2);
+  const __amdgpu_buffer_rsrc_t rb = g8_rsrc(P.B, ((size_t)(P.N - 1) * P.ldb + P.kfull) * 2);
 
   // ---- LDS-DMA source offsets.  One wave-instruction = 1 KiB = 8 rows x 128 B of a half-tile; lane p fills
   // (row 8*piece + p/8, chunk p%8) with the row's 16-byte chunk (p%8) ^ (p/8) (bank swizzle on the SOURCE side).
@@ -186,8 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   {
     int m0, n0, cm;
     tile_origin(0, m0, n0, cm);
-    l_sa = m0 * P.lda * 2;
-    l_sb = n0 * P.ldb * 2;
+    src_off(m0, n0, l_sa, l_sb);
   }
   auto cursor_next = [&]() {
     ++l_k;
@@ -197,8 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     if (l_it < my_tiles) {
       int m0, n0, cm;
       tile_origin(l_it, m0, n0, cm);
-      l_sa = m0 * P.lda * 2;
-      l_sb = n0 * P.ldb * 2;
+      src_off(m0, n0, l_sa, l_sb);
     } else {
       l_sa = l_sb = G8_OOB;                                  // switched off: zero fill, no memory traffic
     }
@@ -317,6 +340,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     if (n0 + wc * 64 < cmin) return;                          // columns owned by the tile on the left (wave-uniform)
     TOUT* C = (TOUT*)P.C;
     const bool up = fr >= 8;
+    const int mlim = row_limit(m0);
+    (void)mlim;
 #pragma unroll
     for (int ii = 0; ii < RH / 2; ++ii) {
       const int i = i0 + ii;
@@ -354,8 +379,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
             recv[e] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send[e]), 0x128, 0xf, 0xf, false));
           f32x4 v1 = up ? recv : lo, v2 = up ? hi : recv;
           float* p = (float*)C + n0 + wc * 64 + cp * 32 + (up ? 16 : 0) + fg * 4;
-          if (row1 < P.M) { float* q1 = p + (size_t)row1 * P.ldc; if (ACCUM) v1 += *(const f32x4*)q1; *(f32x4*)q1 = v1; }
-          if (row2 < P.M) { float* q2 = p + (size_t)row2 * P.ldc; if (ACCUM) v2 += *(const f32x4*)q2; *(f32x4*)q2 = v2; }
+          if (row1 < mlim) { float* q1 = p + (size_t)row1 * P.ldc; if (ACCUM) v1 += *(const f32x4*)q1; *(f32x4*)q1 = v1; }
+          if (row2 < mlim) { float* q2 = p + (size_t)row2 * P.ldc; if (ACCUM) v2 += *(const f32x4*)q2; *(f32x4*)q2 = v2; }
         }
       }
     }
@@ -408,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   auto kstep = [&](auto buf_tag, auto first_tag, bool second, bool last) {
     constexpr int buf = decltype(buf_tag)::value;
     constexpr bool first = decltype(first_tag)::value;
-    const bool full = c_m0 + BM <= P.M && c_n0 >= c_cmin && !ACCUM && !(P.dbg & 1);
+    const bool full = c_m0 + BM <= row_limit(c_m0) && c_n0 >= c_cmin && !ACCUM && !(P.dbg & 1);
     const bool pf = p_pending && p_full;                      // the previous tile's batches were issued in full
     const int x4 = (last && full ? 2 : 0) + (first && pf ? 2 : 0);
     // ph1: r0 x c0
@@ -492,6 +517,7 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
   G8Params P;
   P.A = (const bf16_t*)A; P.B = (const bf16_t*)B; P.C = C;
   P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K;
+  P.ksplit = 1; P.mpad = 0; P.kfull = K;
   P.tiles_n = ceil_div(N, 256);
   const int cus = g8_cus() & ~7;
   const int tiles256 = ceil_div(M, 256) * P.tiles_n;
@@ -522,6 +548,85 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
 }
 
 
+// ---- split K for short inputs ------------------------------------------------------------------------------------------
+// 12 segments per GPU leave the encoder 3072 rows: 24-48 tiles of 128 x 256 for 256 CUs, each walking the whole K
+// (e_dwi, K = 2048: 35 us at 184 TFLOP/s; the cross-attention K|V gradient, K = 6144: 95 us).  With a workspace the
+// product is cut into `ksplit` K ranges that run as separate tiles of the same launch (f32 partial sums in a slab
+// [ksplit][mpad][N]) and one reduce pass sums the slabs in split order into C (bf16 or f32, += for the accumulate form):
+// a fixed summation order, no atomics.  mrmt3_gemm_nt_workspace_bytes() > 0 says when this pays.
+static int g8_splitk_plan(int M, int N, int K, int in_dtype) {
+  const char* e = getenv("MRMT3_GEMM8_SPLITK");              // tuning / A-B switch only
+  if (e && e[0] == '0') return 1;
+  // The second launch and the slab round trip cost ~10 us: measured cold at 3072 rows (profiles/r03_gemm_splitk.txt)
+  // K = 6144 98.8 -> 48.0 us and K = 2048 35.8 -> 29.6 us, but K = 1024 / 1152 22.8 -> 28.6 / 24.6 -> 27.9 us: only
+  // from K = 2048, with >= 512 per split.
+  if (in_dtype != MRMT3_BF16 || M < 1024 || N < 256 || N % 128 != 0 || K < 2048 || K % 128 != 0) return 1;
+  const int cus = g8_cus() & ~7;
+  const int tiles = ceil_div(M, 128) * ceil_div(N, 256);
+  if (tiles * 2 > cus) return 1;                             // the chip is at least half full without a split
+  for (int sp = 4; sp >= 2; --sp)                            // at most one wave of workgroups, >= 512 deep per split
+    if (tiles * sp <= cus && K % sp == 0 && (K / sp) % 128 == 0 && K / sp >= 512) return sp;
+  return 1;
+}
+
+extern "C" size_t mrmt3_gemm_nt_workspace_bytes(int M, int N, int K, int in_dtype) {
+  const int sp = g8_splitk_plan(M, N, K, in_dtype);
+  return sp > 1 ? (size_t)sp * (size_t)(ceil_div(M, 128) * 128) * (size_t)N * sizeof(float) : 0;
+}
+
+template <typename TOUT, bool ACCUM>
+__global__ __launch_bounds__(256) void g8_splitk_reduce_kernel(const float* __restrict__ slab, TOUT* __restrict__ C, int ldc,
+                                                               int M, int N, int mpad, int ksplit) {
+  const int n4 = N >> 2;
+  const size_t total = (size_t)M * n4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), c = (int)(i - (size_t)m * n4) * 4;
+    f32x4 a = *(const f32x4*)(slab + (size_t)m * N + c);
+    for (int z = 1; z < ksplit; ++z) a += *(const f32x4*)(slab + ((size_t)z * mpad + m) * N + c);
+    if constexpr (sizeof(TOUT) == 2) {
+      *(u32x2*)((bf16_t*)C + (size_t)m * ldc + c) = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+    } else {
+      float* q = (float*)C + (size_t)m * ldc + c;
+      if (ACCUM) a += *(const f32x4*)q;
+      *(f32x4*)q = a;
+    }
+  }
+}
+
+// 1 = launched (kernel + reduce), 0 = not a split-K shape or the workspace is too small: use the plain path.
+int mrmt3_gemm_nt8_splitk_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                              int in_dtype, int out_dtype, int accumulate, void* workspace, size_t workspace_bytes,
+                              hipStream_t s) {
+  const int sp = g8_splitk_plan(M, N, K, in_dtype);
+  if (sp <= 1 || !workspace) return 0;
+  const int mpad = ceil_div(M, 128) * 128;
+  if (workspace_bytes < (size_t)sp * mpad * N * sizeof(float) || ((uintptr_t)workspace & 15)) return 0;
+  if (((size_t)M * lda + K) * 2 >= 0x7FFF0000ull || ((size_t)N * ldb + K) * 2 >= 0x7FFF0000ull) return 0;
+  G8Params P;
+  memset(&P, 0, sizeof(P));
+  P.A = (const bf16_t*)A; P.B = (const bf16_t*)B; P.C = workspace;
+  P.lda = lda; P.ldb = ldb; P.ldc = N; P.M = M; P.N = N;
+  P.K = K / sp; P.kfull = K; P.ksplit = sp; P.mpad = mpad;
+  P.tiles_n = ceil_div(N, 256);
+  P.n_tiles = sp * (mpad / 128) * P.tiles_n;
+  { const char* e = getenv("MRMT3_GEMM8_DBG"); P.dbg = e ? atoi(e) : 0; }
+  const int grid = (P.n_tiles + 7) & ~7;
+  hipLaunchKernelGGL((gemm_nt8_kernel<float, false, 4>), dim3((unsigned)grid), dim3(512), 0, s, P);
+  const size_t total = (size_t)M * (N >> 2);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  const float* slab = (const float*)workspace;
+  if (out_dtype == MRMT3_BF16)
+    hipLaunchKernelGGL((g8_splitk_reduce_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, s, slab, (bf16_t*)C, ldc, M, N, mpad, sp);
+  else if (accumulate)
+    hipLaunchKernelGGL((g8_splitk_reduce_kernel<float, true>), dim3((unsigned)blocks), dim3(256), 0, s, slab, (float*)C, ldc, M, N, mpad, sp);
+  else
+    hipLaunchKernelGGL((g8_splitk_reduce_kernel<float, false>), dim3((unsigned)blocks), dim3(256), 0, s, slab, (float*)C, ldc, M, N, mpad, sp);
+  mrmt3_count(MRMT3_CNT_GEMM_NT_SPLITK);
+  return 1;
+}
+
+
 // ---- K2+K7 in one launch: h = x . wi^T and g = dropout(gelu_new(h[:, :dff]) * h[:, dff:]) from the same accumulators.
 // Saves the GEGLU kernel's read of h (rows x 2 dff bf16) and one launch per feed-forward block; h is still written
 // (the backward needs it).  Shapes the fused kernel does not take run as the two separate kernels: same results bit for
@@ -548,6 +653,7 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
   P.A = (const bf16_t*)x; P.B = (const bf16_t*)wi; P.C = h; P.C2 = g;
   P.lda = ldx; P.ldb = ldw; P.ldc = ldh; P.ldc2 = ldg; P.dff = dff;
   P.M = rows; P.N = 2 * dff; P.K = K;
+  P.ksplit = 1; P.mpad = 0; P.kfull = K;
   P.drop = make_drop(p_drop, seed, stream_id, step_dev);
   P.tiles_n = dff / 128;
   const int cus = g8_cus() & ~7;

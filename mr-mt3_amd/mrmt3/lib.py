@@ -28,6 +28,8 @@ _SIGS = {
     "mrmt3_logmel_fwd": (ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp]),
     "mrmt3_logmel_crops_fwd": (ci, [vp, C.c_longlong, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp]),
     "mrmt3_gemm_nt": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
+    "mrmt3_gemm_nt_workspace_bytes": (csz, [ci, ci, ci, ci]),
+    "mrmt3_gemm_nt_ws": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, csz, vp]),
     "mrmt3_gemm_tn_workspace_bytes": (csz, [ci, ci, ci]),
     "mrmt3_gemm_tn": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, csz, vp]),
     "mrmt3_gemm_tn_splits": (ci, [ci, ci, ci]),
@@ -116,7 +118,7 @@ def load():
 
 
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
-                 "attn_bwd_onepass", "attn_f32", "tn_f32")
+                 "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk")
 
 
 def dispatch_counts(reset: bool = False) -> dict:
@@ -230,10 +232,23 @@ def gemm_nt(a, b, out=None, out_dtype=None, accumulate=False):
     fam = "gemm_nt_bf16" if a.dtype == torch.bfloat16 else "gemm_nt_f32"
     if PROFILE is not None:
         PROFILE_BYTES[fam] = PROFILE_BYTES.get(fam, 0.0) + (M * K + N * K) * a.element_size() + M * N * out.element_size()
+    # short inputs with a long K (the encoder at 12 segments per GPU) run split over K through a scratch buffer
+    key = (M, N, K, a.dtype)
+    ws_bytes = _NT_WS.get(key)
+    if ws_bytes is None:
+        ws_bytes = _NT_WS[key] = int(load().mrmt3_gemm_nt_workspace_bytes(M, N, K, _dt(a)))
     with _Timed(fam, 2.0 * M * N * K, "FLOP"):
-        _check(load().mrmt3_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _dt(a),
-                                    _dt(out), int(accumulate), _stream()), "gemm_nt")
+        if ws_bytes:
+            ws = workspace(ws_bytes, a.device)
+            _check(load().mrmt3_gemm_nt_ws(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _dt(a),
+                                           _dt(out), int(accumulate), _p(ws), ws.numel(), _stream()), "gemm_nt_ws")
+        else:
+            _check(load().mrmt3_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _dt(a),
+                                        _dt(out), int(accumulate), _stream()), "gemm_nt")
     return out
+
+
+_NT_WS = {}          # (M, N, K, dtype) -> scratch bytes of the split-K form (0: the shape does not split)
 
 
 _ws_cache = {}

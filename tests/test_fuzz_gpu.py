@@ -65,6 +65,40 @@ def test_gemm_nt_random_shapes_across_the_dispatch_boundaries(dev, M, N, K, od):
         assert torch.equal(out2, out)                                   # same bits in a different buffer
 
 
+@pytest.mark.parametrize("M,N,K,od", [(3072, 512, 2048, "bf16"), (3072, 512, 6144, "f32+"), (3000, 512, 2048, "bf16"),
+                                      (4096, 1024, 2048, "f32"), (1024, 256, 4096, "bf16"), (2049, 384, 3072, "bf16"),
+                                      (6144, 512, 2048, "f32"), (3072, 512, 2304, "bf16")])
+def test_gemm_nt_split_over_k_for_short_inputs(dev, M, N, K, od):
+    """mrmt3_gemm_nt_ws: short inputs with a long K (the encoder's rows at 12 segments per GPU) run as 2-4 K ranges of one
+    launch + a reduce in split order.  Against f32 torch, bitwise repeatable, guard rows untouched, the dispatch
+    counter says the split form ran, and the plain entry point (no workspace) gives the same values to bf16 rounding."""
+    from mrmt3 import lib
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    b = (torch.randn(N, K, generator=g) * 0.05).to(dev).bfloat16()
+    odt = torch.bfloat16 if od == "bf16" else torch.float32
+    assert lib.load().mrmt3_gemm_nt_workspace_bytes(M, N, K, 1) > 0, "not a split-K shape"
+    buf = torch.full((M + 3, N), 3.0, device=dev, dtype=odt)
+    out = buf[:M]
+    lib.dispatch_counts(reset=True)
+    lib.gemm_nt(a, b, out=out, accumulate=(od == "f32+"))
+    assert lib.dispatch_counts()["gemm_nt_splitk"] == 1
+    ref = a.float() @ b.float().t() + (3.0 if od == "f32+" else 0.0)
+    err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (1e-2 if od == "bf16" else 5e-6), err
+    assert (buf[M:] == 3.0).all()
+    out2 = torch.full((M, N), 3.0, device=dev, dtype=odt)
+    lib.gemm_nt(a, b, out=out2, accumulate=(od == "f32+"))
+    assert torch.equal(out, out2)
+    # the plain entry point on the same operands
+    out3 = torch.full((M, N), 3.0, device=dev, dtype=odt)
+    L = lib.load()
+    rc = L.mrmt3_gemm_nt(lib._p(a), a.stride(0), lib._p(b), b.stride(0), lib._p(out3), out3.stride(0), M, N, K, 1,
+                         1 if od == "bf16" else 0, int(od == "f32+"), lib._stream())
+    assert rc == 0
+    assert (out3.float() - out.float()).abs().max().item() / ref.abs().max().item() < (1e-2 if od == "bf16" else 5e-6)
+
+
 def _tn_shapes(n, seed):
     r = np.random.RandomState(seed)
     out = [(int(r.choice(EDGE_M)) if i % 2 else int(r.randint(1, 70000)), 8 * int(r.randint(1, 260)), 8 * int(r.randint(1, 130)))
