@@ -657,9 +657,12 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
   P.drop = make_drop(p_drop, seed, stream_id, step_dev);
   P.tiles_n = dff / 128;
   const int cus = g8_cus() & ~7;
-  const int tiles256 = ceil_div(rows, 256) * P.tiles_n;
-  const bool small = tiles256 < cus;
-  P.n_tiles = small ? ceil_div(rows, 128) * P.tiles_n : tiles256;
+  const int tiles256 = ceil_div(rows, 256) * P.tiles_n, tiles128 = ceil_div(rows, 128) * P.tiles_n;
+  // 128-row tiles when there are too few 256-row tiles for the chip, or when they come in a badly filled last wave and
+  // the 128-row tiling does not (12 segments per GPU: 384 tiles = 1.5 waves against 768 = 3 waves)
+  auto fill = [&](int nt) { return (double)nt / ((double)ceil_div(nt, cus) * cus); };
+  const bool small = tiles256 < cus || (tiles256 < 4 * cus && fill(tiles128) > fill(tiles256) + 0.15);
+  P.n_tiles = small ? tiles128 : tiles256;
   { const char* e = getenv("MRMT3_GEMM8_DBG"); P.dbg = e ? atoi(e) : 0; }
   P.skew_ticks = 0;
   int grid = P.n_tiles < cus ? ((P.n_tiles + 7) & ~7) : cus;
