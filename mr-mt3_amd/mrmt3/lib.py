@@ -113,10 +113,14 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if not os.environ.get("MRMT3_TOOL_LIB") and lib.mrmt3_version() < MIN_VERSION:
+        raise RuntimeError(f"{LIB_PATH} is version {lib.mrmt3_version()}, this binding needs >= {MIN_VERSION}: "
+                           "a stale build — run `make -C mr-mt3_amd/csrc`")
     _lib = lib
     return lib
 
 
+MIN_VERSION = 103
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk")
 
