@@ -156,8 +156,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     }
     return P.M;
   };
-  const __amdgpu_buffer_rsrc_t ra = g8_rsrc(P.A, ((size_t)(P.M - 1) * P.lda + P.kfull) * 2);
-  const __amdgpu_buffer_rsrc_t rb = g8_rsrc(P.B, ((size_t)(P.N - 1) * P.ldb + P.kfull) * 2);
+  const int kcols = SPLITK ? P.kfull : P.K;                   // (columns of the operands; P.K is the depth of a tile)
+  const __amdgpu_buffer_rsrc_t ra = g8_rsrc(P.A, ((size_t)(P.M - 1) * P.lda + kcols) * 2);
+  const __amdgpu_buffer_rsrc_t rb = g8_rsrc(P.B, ((size_t)(P.N - 1) * P.ldb + kcols) * 2);
 
   // ---- LDS-DMA source offsets.  One wave-instruction = 1 KiB = 8 rows x 128 B of a half-tile; lane p fills
   // (row 8*piece + p/8, chunk p%8) with the row's 16-byte chunk (p%8) ^ (p/8) (bank swizzle on the SOURCE side).

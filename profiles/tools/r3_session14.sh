@@ -1,8 +1,9 @@
 #!/bin/bash
+# round-3 GPU session 14: the whole GPU suite, smoke, the bench line on the final tree
 mkdir -p gpurun_out/r3
 O=gpurun_out/r3
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-MRMT3_DDP_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-inference --extra-batch 0 > $O/bench_forced_collectives_world1.json 2> $O/bench_forced_collectives_world1.err; python3 -c "
-import json;d=json.load(open('$O/bench_forced_collectives_world1.json'));print('forced collectives, world 1:',round(d['ms_per_step'],3),'ms', d['collectives'], 'graph segments', d['graph_segments'], 'host issue', round(d['host_issue_ms_per_step'],2))" || tail -5 $O/bench_forced_collectives_world1.err
-MRMT3_DDP_FORCE_COLLECTIVES=1 MRMT3_GRAD_EXCHANGE=bf16 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-inference --extra-batch 0 --no-roofline 2>/dev/null | python3 -c "
-import json,sys;d=json.loads(sys.stdin.read());print('forced collectives, bf16 exchange:',round(d['ms_per_step'],3),'ms')"
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/t_all.log 2>&1; tail -4 $O/t_all.log
+timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_final3.json 2> $O/bench_final3.err; python3 -c "
+import json;d=json.load(open('$O/bench_final3.json'));print('bench:',round(d['value'],1),'seg/s',round(d['ms_per_step'],3),'ms; b12',d['train_b12']['ms_per_step'],'roofline',round(d['roofline']['frac'],4))"
