@@ -897,19 +897,25 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 // HBM read), statistics by wave shuffles.  A wave walks CE_RPW consecutive rows and the workgroup adds its
 // loss contribution with ONE atomic: one atomic per row (65 536 of them on a single address) cost more
 // than the whole rest of the kernel.
-#define CE_RPW 16
+// Rows per wave: as few as keep the launch at ~2048 workgroups (a wave walks its rows one after the other, each a
+// load -> max -> exp -> sum -> store chain of ~3.5 us: at 16 rows per wave a 16 384-row chunk ran 4 waves per CU and
+// 2.6 TB/s; at 2 rows per wave the CUs are full), at most 16.
+static inline int ce_rows_per_wave(int rows) {
+  int r = rows / (4 * 2048);
+  return r < 1 ? 1 : (r > 16 ? 16 : r);
+}
 template <typename TD, int NV>
 __global__ __launch_bounds__(256) void ce_wave_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
                                                       const float* __restrict__ denom, float* __restrict__ loss,
                                                       TD* __restrict__ dlogits, int rows, int weighted, int lo, int hi,
-                                                      float grad_scale) {
+                                                      float grad_scale, int rpw) {
   constexpr int V = NV * 256;
   __shared__ float part[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * CE_RPW;
+  const int row0 = (blockIdx.x * 4 + wave) * rpw;
   const float inv_den = 1.f / denom[0];
   float acc = 0.f;
-  for (int row = row0; row < min(row0 + CE_RPW, rows); ++row) {
+  for (int row = row0; row < min(row0 + rpw, rows); ++row) {
     const float* lp = logits + (size_t)row * V;
     const int64_t t = targets[row];
     float w, n;
@@ -969,10 +975,11 @@ extern "C" int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, con
   MR_CHECK_ARG(logits && targets && denom_dev && loss_dev && rows > 0 && V % 4 == 0, "ce_fwd_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (V == 1536 || V == 1024 || V == 2048 || V == 512) {
-    dim3 grid((unsigned)ceil_div(rows, 4 * CE_RPW)), block(256);
+    const int rpw = ce_rows_per_wave(rows);
+    dim3 grid((unsigned)ceil_div(rows, 4 * rpw)), block(256);
 #define CEW(TD, NV)                                                                                              \
   hipLaunchKernelGGL((ce_wave_kernel<TD, NV>), grid, block, 0, s, logits, targets, denom_dev, loss_dev, (TD*)dlogits, \
-                     rows, weighted, inst_lo, inst_hi, grad_scale)
+                     rows, weighted, inst_lo, inst_hi, grad_scale, rpw)
 #define CEV(TD)                                  \
   do {                                           \
     if (V == 1536) CEW(TD, 6);                   \
