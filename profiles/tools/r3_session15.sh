@@ -1,6 +1,12 @@
 #!/bin/bash
+# round-3 GPU session 15: rocprofv3 kernel trace + stats of the bench command on the final tree
 mkdir -p gpurun_out/r3
 O=gpurun_out/r3
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 900 python bench.py > $O/bench_default.out 2> $O/bench_default.err; echo "stdout lines: $(wc -l < $O/bench_default.out)"; head -c 300 $O/bench_default.out; echo
-MRMT3_DDP_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-inference --extra-batch 0 --no-roofline > $O/bench_fc.out 2> $O/bench_fc.err; echo "stdout lines under torchrun with RCCL: $(wc -l < $O/bench_fc.out)"; head -c 200 $O/bench_fc.out; echo
+rm -rf $O/prof_final
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_final -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-inference --extra-batch 0 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+python3 profiles/tools/step_breakdown.py $O/prof_final > $O/r03_step_breakdown.txt 2>&1; head -16 $O/r03_step_breakdown.txt
+cp $(find $O/prof_final -name "*kernel_stats.csv" | head -1) $O/r03_bench_kernel_stats.csv
+find $O/prof_final -name "*kernel_trace.csv" -delete; find $O/prof_final -name "*.db" -delete
+python3 -c "
+import json;d=json.load(open('$O/bench_under_rocprof.json'));r=d['roofline'];print('under rocprof:',round(d['ms_per_step'],3),'ms; gemm_nt family avg launch',round(r['avg_launch_ms']*1e3,1),'us, launches',r['launches'],'frac',round(r['frac'],4))"
