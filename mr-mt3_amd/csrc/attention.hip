@@ -37,7 +37,7 @@ static int attn_tile_mode() {
   return e ? (int)strtol(e, nullptr, 0) : 5;
 }
 
-template <bool PAIR, bool DROP>
+template <bool PAIR, bool DROP, int RT = 2>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
   const unsigned drop_bh = P.drop.seed + step_salt(P.drop.step) + (unsigned)(b * P.H + h) * DROP_CB;
-  const int n_qt = ceil_div(P.Lq, 128);
+  const int n_qt = ceil_div(P.Lq, 64 * RT);
   const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk), vres = rows_rsrc(vb, P.Lk, P.ldv);
   const unsigned k_lane = rows8_lane_off(P.ldk, lane), v_lane = rows8_lane_off(P.ldv, lane);
 
@@ -63,24 +63,24 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     if (pass == 1 && 2 * tile_ == n_qt - 1) break;
     if (pass == 1) __syncthreads();      // every wave is done reading the previous tile's LDS stages
   }
-  const int q0 = q_tile * 128;
+  const int q0 = q_tile * (64 * RT);
 
   // Q fragments (B operand): lane holds Q[q = qrow(qt)][d = 32ks + 8g .. +7]
-  bf16x8 qf[2][2];
-  int qrow[2];
-  unsigned drop_q[2];     // the lane's part of the mask argument: head, query row, key group 4g..4g+3 inside a 16-key tile
+  bf16x8 qf[RT][2];
+  int qrow[RT];
+  unsigned drop_q[RT];     // the lane's part of the mask argument: head, query row, key group 4g..4g+3 inside a 16-key tile
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    qrow[qt] = q0 + uw * 32 + qt * 16 + fr;
+  for (int qt = 0; qt < RT; ++qt) {
+    qrow[qt] = q0 + uw * (16 * RT) + qt * 16 + fr;
     drop_q[qt] = drop_bh + (unsigned)qrow[qt] * DROP_CQ + (unsigned)fg * DROP_CK;
     const int r = min(qrow[qt], P.Lq - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *(const bf16x8*)(qb + (size_t)r * P.ldq + ks * 32 + fg * 8);
   }
-  f32x4 oT[2][4];
-  float m_run[2], l_run[2];
+  f32x4 oT[RT][4];
+  float m_run[RT], l_run[RT];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < RT; ++qt) {
     m_run[qt] = -INFINITY;
     l_run[qt] = 0.f;
 #pragma unroll
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   }
 
   int n_kv = ceil_div(P.Lk, 64);
-  if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
+  if (P.causal) n_kv = min(n_kv, (min(q0 + 64 * RT - 1, P.Lq - 1)) / 64 + 1);
   // each wave stages 16 rows of K and of V per tile (2 + 2 wave-instructions); `on` = false turns the tile into
   // four zero-fills that never leave the CU, which keeps the vmcnt arithmetic of the loop uniform
   auto stage = [&](int buf, int kv0, bool on) {
@@ -118,22 +118,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     // at every back-edge — 72 v_mov per tile, 16 % of the loop's vector instructions — while the skipped waves only
     // waited at the next barrier.)
     // S^T = K . Q^T : sT[qt][kt] holds S^T[key = kt*16 + 4g + r][q = fr]
-    f32x4 sT[2][4];
+    f32x4 sT[RT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       bf16x8 ka0 = lds_row8(lk, kt * 16 + fr, fg);
       bf16x8 ka1 = lds_row8(lk, kt * 16 + fr, 4 + fg);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < RT; ++qt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mfma16(ka0, qf[qt][0], acc);
         acc = mfma16(ka1, qf[qt][1], acc);
         sT[qt][kt] = acc;
       }
     }
-    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * 32);
+    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * (16 * RT));
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < RT; ++qt) {
       if (__builtin_expect(need_mask, 0)) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -183,21 +183,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     // O^T += V^T . P^T : k-slot (g, j) of a 32-key step <-> key = 32*ks + 16*(j>>2) + 4g + (j&3)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 pb[2];
+      bf16x8 pb[RT];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) pb[qt] = pack8(sT[qt][2 * ks], sT[qt][2 * ks + 1]);
+      for (int qt = 0; qt < RT; ++qt) pb[qt] = pack8(sT[qt][2 * ks], sT[qt][2 * ks + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x8 vt = lds_tr8(lv, ks * 32 + fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) oT[qt][dt] = mfma16(vt, pb[qt], oT[qt][dt]);
+        for (int qt = 0; qt < RT; ++qt) oT[qt][dt] = mfma16(vt, pb[qt], oT[qt][dt]);
       }
     }
   }
   VMCNT(0);      // the switched-off prefetches of the last two iterations still write their zeros
 
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < RT; ++qt) {
     float l = l_run[qt];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
 #define QD_STAGES 4
 #define QD_STAGE_BYTES 8448   // Q 4 KiB + dO 4 KiB + 64 floats
 
-template <bool PAIR, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
+template <bool PAIR, bool DROP, int RT = 2>
+__global__ __launch_bounds__(256, RT == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[QD_STAGES * QD_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   const float* lse = P.lse + ((size_t)b * P.H + h) * P.Lq;
   const float* dlt = P.delta + ((size_t)b * P.H + h) * P.Lq;
   const unsigned drop_bh = P.drop.seed + step_salt(P.drop.step) + (unsigned)(b * P.H + h) * DROP_CB;
-  const int n_kt = ceil_div(P.Lk, 128);
+  const int n_kt = ceil_div(P.Lk, 64 * RT);
   const __amdgpu_buffer_rsrc_t qres = rows_rsrc(qb, P.Lq, P.ldq), dores = rows_rsrc(dob, P.Lq, P.lddo);
   const unsigned q_lane = rows8_lane_off(P.ldq, lane), do_lane = rows8_lane_off(P.lddo, lane);
 
@@ -256,17 +256,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
     if (pass == 1 && 2 * tile_ == n_kt - 1) break;
     if (pass == 1) __syncthreads();
   }
-  const int k0 = k_tile * 128;
+  const int k0 = k_tile * (64 * RT);
 
-  bf16x8 kf[2][2], vf[2][2];
-  int key[2];
+  bf16x8 kf[RT][2], vf[RT][2];
+  int key[RT];
   // mask: the lane computes the word of query (fg*4 + fp) of each 16-query tile for its key's group of four; its own
   // element sits in byte (key & 3) = fp of every word of the quad
-  unsigned drop_k[2];
+  unsigned drop_k[RT];
   const unsigned drop_bmask = 0xFFu << (8 * fp), drop_bthr = P.drop.thresh8 << (8 * fp);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    key[nt] = k0 + uw * 32 + nt * 16 + fr;
+  for (int nt = 0; nt < RT; ++nt) {
+    key[nt] = k0 + uw * (16 * RT) + nt * 16 + fr;
     drop_k[nt] = drop_bh + ((unsigned)key[nt] >> 2) * DROP_CK + (unsigned)(fg * 4 + fp) * DROP_CQ;
     const int r = min(key[nt], P.Lk - 1);
 #pragma unroll
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
       vf[nt][ks] = *(const bf16x8*)(vb + (size_t)r * P.ldv + ks * 32 + fg * 8);
     }
   }
-  f32x4 dkT[2][4], dvT[2][4];
+  f32x4 dkT[RT][4], dvT[RT][4];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int nt = 0; nt < RT; ++nt)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dkT[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -309,11 +309,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
     // causal: a query block entirely above this wave's 32 keys contributes nothing to them
     // ... and a wave whose 32 keys all lie past the end of the sequence (ragged last key tile, e.g. 256 encoder
     // frames + 64 memory slots = 320 keys) has nothing to compute at all
-    const bool wave_active = (k0 + uw * 32 < P.Lk) && !(P.causal && qb0 + 31 < k0 + uw * 32);
+    const bool wave_active = (k0 + uw * (16 * RT) < P.Lk) && !(P.causal && qb0 + 31 < k0 + uw * (16 * RT));
     if (wave_active) {
-    const bool need_mask = (qb0 + 32 > P.Lq) || (k0 + uw * 32 + 32 > P.Lk) || (P.causal && qb0 < k0 + uw * 32 + 31);
-    bf16x8 pdB[2], dsB[2];  // per key tile: B operands built from both query tiles
-    f32x4 pd[2][2], ds[2][2];  // [qt][nt]
+    const bool need_mask = (qb0 + 32 > P.Lq) || (k0 + uw * (16 * RT) + 16 * RT > P.Lk) || (P.causal && qb0 < k0 + uw * (16 * RT) + 16 * RT - 1);
+    bf16x8 pdB[RT], dsB[RT];  // per key tile: B operands built from both query tiles
+    f32x4 pd[2][RT], ds[2][RT];  // [qt][nt]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       bf16x8 qa0 = lds_row8(lq, qt * 16 + fr, fg);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
         drow[r] = lstat[32 + qt * 16 + fg * 4 + r];
       }
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < RT; ++nt) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
         s = mfma16(qa0, kf[nt][0], s);
         s = mfma16(qa1, kf[nt][1], s);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
       }
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < RT; ++nt) {
       pdB[nt] = pack8(pd[0][nt], pd[1][nt]);  // k-slot (g,j) <-> q = 16*(j>>2) + 4g + (j&3)
       dsB[nt] = pack8(ds[0][nt], ds[1][nt]);
     }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
       bf16x8 dot_ = lds_tr8(ldo_, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
       bf16x8 qt_ = lds_tr8(lq, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < RT; ++nt) {
         dvT[nt][dt] = mfma16(dot_, pdB[nt], dvT[nt][dt]);
         dkT[nt][dt] = mfma16(qt_, dsB[nt], dkT[nt][dt]);
       }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
   }
   VMCNT(0);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < RT; ++nt) {
     if (key[nt] >= P.Lk) continue;
     bf16_t* dkrow = P.dk + ((size_t)b * P.Lk + key[nt]) * P.lddk + h * HD;
     bf16_t* dvrow = P.dv + ((size_t)b * P.Lk + key[nt]) * P.lddv + h * HD;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams P) {
 // kernel waits on dependent LDS-read -> MFMA -> exp chains more than it issues, and a third wave per SIMD measured
 // -4 % on the decoder's self-attention backward (profiles/r03_attn_micro.txt).  The dK/dV kernel stays at two: at 168
 // registers it spills 39 and runs 1.6x slower.
-template <bool PAIR, bool DROP>
+template <bool PAIR, bool DROP, int RT = 2>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[KV_STAGES * KV_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
   const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
   const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
   const unsigned drop_bh = P.drop.seed + step_salt(P.drop.step) + (unsigned)(b * P.H + h) * DROP_CB;
-  const int n_qt = ceil_div(P.Lq, 128);
+  const int n_qt = ceil_div(P.Lq, 64 * RT);
   const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk), vres = rows_rsrc(vb, P.Lk, P.ldv);
   const unsigned k_lane = rows8_lane_off(P.ldk, lane), v_lane = rows8_lane_off(P.ldv, lane);
 
@@ -428,15 +428,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
     if (pass == 1 && 2 * tile_ == n_qt - 1) break;
     if (pass == 1) __syncthreads();
   }
-  const int q0 = q_tile * 128;
+  const int q0 = q_tile * (64 * RT);
 
-  bf16x8 qf[2][2], dof[2][2];
-  int qrow[2];
-  unsigned drop_q[2];
-  float lse_q[2], dlt_q[2];
+  bf16x8 qf[RT][2], dof[RT][2];
+  int qrow[RT];
+  unsigned drop_q[RT];
+  float lse_q[RT], dlt_q[RT];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    qrow[qt] = q0 + uw * 32 + qt * 16 + fr;
+  for (int qt = 0; qt < RT; ++qt) {
+    qrow[qt] = q0 + uw * (16 * RT) + qt * 16 + fr;
     drop_q[qt] = drop_bh + (unsigned)qrow[qt] * DROP_CQ + (unsigned)fg * DROP_CK;
     const int r = min(qrow[qt], P.Lq - 1);
 #pragma unroll
@@ -466,14 +466,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
     dlt_q[qt] = part;
     if (fg == 0 && qrow[qt] < P.Lq) P.delta[((size_t)b * P.H + h) * P.Lq + r] = part;
   }
-  f32x4 dqT[2][4];
+  f32x4 dqT[RT][4];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < RT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dqT[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int n_kv = ceil_div(P.Lk, 64);
-  if (P.causal) n_kv = min(n_kv, (min(q0 + 127, P.Lq - 1)) / 64 + 1);
+  if (P.causal) n_kv = min(n_kv, (min(q0 + 64 * RT - 1, P.Lq - 1)) / 64 + 1);
   auto stage = [&](int buf, int kv0, bool on) {      // as in the forward kernel
     unsigned char* base = lds + buf * KV_STAGE_BYTES;
 #pragma unroll
@@ -496,8 +496,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
     const unsigned char* lv = lk + 8192;
     cur = cur == KV_STAGES - 1 ? 0 : cur + 1;
     // (no per-wave skip of the fully masked last causal tile: see the forward kernel)
-    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * 32);
-    f32x4 dsT[2][4];  // [qt][kt] : dS^T[key = kt*16+4g+r][q = fr]
+    const bool need_mask = (kv0 + 64 > P.Lk) || (P.causal && kv0 + 63 > q0 + uw * (16 * RT));
+    f32x4 dsT[RT][4];  // [qt][kt] : dS^T[key = kt*16+4g+r][q = fr]
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       bf16x8 ka0 = lds_row8(lk, kt * 16 + fr, fg);
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
       bf16x8 va0 = lds_row8(lv, kt * 16 + fr, fg);
       bf16x8 va1 = lds_row8(lv, kt * 16 + fr, 4 + fg);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < RT; ++qt) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
         s = mfma16(ka0, qf[qt][0], s);
         s = mfma16(ka1, qf[qt][1], s);
@@ -533,20 +533,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 db[2];
+      bf16x8 db[RT];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) db[qt] = pack8(dsT[qt][2 * ks], dsT[qt][2 * ks + 1]);
+      for (int qt = 0; qt < RT; ++qt) db[qt] = pack8(dsT[qt][2 * ks], dsT[qt][2 * ks + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x8 kt_ = lds_tr8(lk, ks * 32 + fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) dqT[qt][dt] = mfma16(kt_, db[qt], dqT[qt][dt]);
+        for (int qt = 0; qt < RT; ++qt) dqT[qt][dt] = mfma16(kt_, db[qt], dqT[qt][dt]);
       }
     }
   }
   VMCNT(0);
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < RT; ++qt) {
     if (qrow[qt] >= P.Lq) continue;
     bf16_t* row = P.dq + ((size_t)b * P.Lq + qrow[qt]) * P.lddq + h * HD;
 #pragma unroll
@@ -591,6 +591,14 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
   P.tile_mode = attn_tile_mode();
   const bool pair = attn_paired(Lq, causal, H, B);
+  if (attn_fine(Lq, pair, H, B)) {                          // small launch: 64-row tiles
+    const dim3 gf(ceil_div(Lq, 64), H, B);
+    if (P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<false, true, 1>), gf, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 1>), gf, dim3(256), 0, s, P);
+    MR_CHECK_LAUNCH("attn_fwd");
+    mrmt3_count(MRMT3_CNT_ATTN_FWD);
+    return MRMT3_OK;
+  }
   const dim3 grid(attn_grid_x(Lq, pair), H, B);
   if (pair && P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, P);
   else if (pair) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, P);
@@ -629,11 +637,22 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   const bool pair_q = attn_paired(Lq, causal, H, B), pair_k = attn_paired(Lk, causal, H, B);
   const dim3 gq(attn_grid_x(Lq, pair_q), H, B), gk(attn_grid_x(Lk, pair_k), H, B);
   const bool drop = P.drop.thresh8 != 0;
+  const bool fine_q = attn_fine(Lq, pair_q, H, B), fine_k = attn_fine(Lk, pair_k, H, B);
+  if (fine_q) {
+    const dim3 gf(ceil_div(Lq, 64), H, B);
+    if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true, 1>), gf, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, 1>), gf, dim3(256), 0, s, P);
+  } else
   if (pair_q && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, dim3(256), 0, s, P);
   else if (pair_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), 0, s, P);
   else if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, dim3(256), 0, s, P);
   MR_CHECK_LAUNCH("attn_bwd dq");
+  if (fine_k) {
+    const dim3 gf(ceil_div(Lk, 64), H, B);
+    if (drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, true, 1>), gf, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, false, 1>), gf, dim3(256), 0, s, P);
+  } else
   if (pair_k && drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, true>), gk, dim3(256), 0, s, P);
   else if (pair_k) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, false>), gk, dim3(256), 0, s, P);
   else if (drop) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, true>), gk, dim3(256), 0, s, P);

@@ -139,6 +139,7 @@ __device__ __forceinline__ void attn_tile(int& tile, int& h, int& b, int mode) {
   // (whole (batch, head) groups flip — the position of the group's first tile in its XCD's share decides, a function of
   // bh alone — so the map stays a bijection for any nt, H, B)
   if (mode & 16) tile = (tile & 1) ? nt - 1 - (tile >> 1) : (tile >> 1);
+  if (mode & 32) tile = nt - 1 - tile;
   if ((mode & 15) && ((((bh * nt) % ((n & 7) == 0 ? (n >> 3) : n)) >> (mode & 15)) & 1) != 0) tile = nt - 1 - tile;
   h = bh % H;
   b = bh / H;
@@ -149,6 +150,15 @@ __device__ __forceinline__ void attn_tile(int& tile, int& h, int& b, int mode) {
 static inline bool attn_paired(int L, int causal, int H, int B) {
   const int n = ceil_div(L, 128);
   return causal && n >= 2 && ((n + 1) / 2) * H * B >= 512;
+}
+// Small launches (12 segments per GPU: 72 (batch, head) pairs) do not fill the chip with 128-row tiles — the encoder's
+// self-attention is 144 workgroups, the decoder's 576 unequal ones for 768 slots: such launches run 64-row tiles
+// (16 rows per wave, RT = 1 instantiations) instead, twice the workgroups.  MRMT3_ATTN_FINE=0 / 1 forces it (tuning).
+static inline bool attn_fine(int L, bool paired, int H, int B) {
+  if (paired || L <= 64) return false;
+  const char* e = getenv("MRMT3_ATTN_FINE");                // (read per call: tests switch it)
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return (long long)ceil_div(L, 128) * H * B < 768;
 }
 static inline int attn_grid_x(int L, bool paired) {
   const int n = ceil_div(L, 128);

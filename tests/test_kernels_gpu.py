@@ -342,8 +342,16 @@ ATTN_SHAPES = [(2, 6, 256, 256, False), (2, 6, 1024, 1024, True), (1, 6, 1024, 3
                (22, 6, 1024, 1024, True), (36, 6, 640, 640, True)]
 
 
+@pytest.fixture(params=["coarse", "fine"])
+def tile_rows(request, monkeypatch):
+    """128-row tiles (32 rows per wave) or the 64-row tiles small launches take (attn_fine, csrc/attn_common.h): every
+    attention shape below runs both instantiations (paired causal launches are coarse either way)."""
+    monkeypatch.setenv("MRMT3_ATTN_FINE", "1" if request.param == "fine" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", ATTN_SHAPES)
-def test_attn_fwd_bf16(dev, B, H, Lq, Lk, causal):
+def test_attn_fwd_bf16(dev, tile_rows, B, H, Lq, Lk, causal):
     from mrmt3 import lib
     g = torch.Generator(device="cpu").manual_seed(Lq * 7 + Lk)
     q = (torch.randn(B * Lq, H * 64, generator=g) * 0.35).to(dev).bfloat16()
@@ -367,7 +375,7 @@ def test_attn_fwd_fused_qkv_layout(dev):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", ATTN_SHAPES)
-def test_attn_bwd_bf16(dev, B, H, Lq, Lk, causal):
+def test_attn_bwd_bf16(dev, tile_rows, B, H, Lq, Lk, causal):
     from mrmt3 import lib
     g = torch.Generator(device="cpu").manual_seed(Lq * 3 + Lk)
     q = (torch.randn(B * Lq, H * 64, generator=g) * 0.35).to(dev).bfloat16()
@@ -439,7 +447,7 @@ def test_attn_online_softmax_rescale_branch(dev):
 
 
 @pytest.mark.parametrize("B,H,L,causal", [(1, 2, 256, False), (2, 4, 512, True), (1, 3, 384, True), (64, 6, 1024, True)])
-def test_attn_dropout_statistics_and_bwd_mask(dev, B, H, L, causal):
+def test_attn_dropout_statistics_and_bwd_mask(dev, tile_rows, B, H, L, causal):
     """Uniform attention (q = k = 0, v = 1): every output is (#kept / #visible) / 0.9.  The causal cases run the
     paired-tile instantiations (an even and an odd number of 128-row tiles, with and without the XCD remap); the last
     case is the decoder self-attention of the benchmark batch at full size."""
@@ -469,7 +477,7 @@ def test_attn_dropout_statistics_and_bwd_mask(dev, B, H, L, causal):
 
 
 @pytest.mark.parametrize("B,H,Lq,causal", [(2, 3, 200, False), (1, 2, 64, True)])
-def test_attn_dropout_mask_equals_the_restatement(dev, B, H, Lq, causal):
+def test_attn_dropout_mask_equals_the_restatement(dev, tile_rows, B, H, Lq, causal):
     """Uniform scores and V = identity over 64 keys make the output the dropped probability matrix itself:
     O[q, k] = keep[q, k] * scale / (#visible keys).  The kept set must equal oracle/dropout_ref.attn_keep_mask, and
     dV = Pd^T dO must come from the same mask in the backward kernels."""
@@ -507,7 +515,7 @@ def test_attn_dropout_mask_equals_the_restatement(dev, B, H, Lq, causal):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-def test_attn_dropout_mask_element_by_element_in_every_backward_product(dev, causal):
+def test_attn_dropout_mask_element_by_element_in_every_backward_product(dev, tile_rows, causal):
     """32 queries x 32 keys with K[k] = e_k, Q[q] = e_(32+q), V[k] = e_k and dO = 1: the scores are all zero (uniform
     P), dP[q, k] = 1, so dS[q, k] = P (keep[q, k] * scale - delta_q) takes two values per row and
       dQ[q, k]      = dS[q, k]   (the dQ kernel's mask, query on the lane),
