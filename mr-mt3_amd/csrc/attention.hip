@@ -591,7 +591,7 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
   P.tile_mode = attn_tile_mode();
   const bool pair = attn_paired(Lq, causal, H, B);
-  if (attn_fine(Lq, pair, H, B)) {                          // small launch: 64-row tiles
+  if (attn_fine(Lq, pair, causal, H, B)) {                          // small launch: 64-row tiles
     const dim3 gf(ceil_div(Lq, 64), H, B);
     if (P.drop.thresh8) hipLaunchKernelGGL((attn_fwd_kernel<false, true, 1>), gf, dim3(256), 0, s, P);
     else hipLaunchKernelGGL((attn_fwd_kernel<false, false, 1>), gf, dim3(256), 0, s, P);
@@ -637,7 +637,7 @@ extern "C" int mrmt3_attn_bwd(const void* q, int ldq, const void* k, int ldk, co
   const bool pair_q = attn_paired(Lq, causal, H, B), pair_k = attn_paired(Lk, causal, H, B);
   const dim3 gq(attn_grid_x(Lq, pair_q), H, B), gk(attn_grid_x(Lk, pair_k), H, B);
   const bool drop = P.drop.thresh8 != 0;
-  const bool fine_q = attn_fine(Lq, pair_q, H, B), fine_k = attn_fine(Lk, pair_k, H, B);
+  const bool fine_q = attn_fine(Lq, pair_q, causal, H, B), fine_k = attn_fine(Lk, pair_k, causal, H, B);
   if (fine_q) {
     const dim3 gf(ceil_div(Lq, 64), H, B);
     if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true, 1>), gf, dim3(256), 0, s, P);

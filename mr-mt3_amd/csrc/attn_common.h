@@ -154,11 +154,14 @@ static inline bool attn_paired(int L, int causal, int H, int B) {
 // Small launches (12 segments per GPU: 72 (batch, head) pairs) do not fill the chip with 128-row tiles — the encoder's
 // self-attention is 144 workgroups, the decoder's 576 unequal ones for 768 slots: such launches run 64-row tiles
 // (16 rows per wave, RT = 1 instantiations) instead, twice the workgroups.  MRMT3_ATTN_FINE=0 / 1 forces it (tuning).
-static inline bool attn_fine(int L, bool paired, int H, int B) {
+static inline bool attn_fine(int L, bool paired, int causal, int H, int B) {
   if (paired || L <= 64) return false;
   const char* e = getenv("MRMT3_ATTN_FINE");                // (read per call: tests switch it)
   if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-  return (long long)ceil_div(L, 128) * H * B < 768;
+  // causal launches that are too small to pair (up to 21 segments) have unequal tiles: the finer grain balances them
+  // (20 segments: forward 54.8 -> 50.0 us, backward 148.4 -> 131.2 us); equal tiles only while the chip is underfilled
+  // (cross-attention forward at 16-32 segments is 7-10 % slower with 64-row tiles)
+  return causal || (long long)ceil_div(L, 128) * H * B < 768;
 }
 static inline int attn_grid_x(int L, bool paired) {
   const int n = ceil_div(L, 128);
