@@ -57,10 +57,19 @@ struct G8Params {
   // per-split depth) of `kfull` columns, written as f32 to a slab [ksplit][mpad][N] (C = the slab, ldc = N); row tile
   // indices run over ksplit * mpad VIRTUAL rows.  ksplit = 1: kfull = K, mpad unused.
   int ksplit, mpad, kfull;
+  int nt_c;            // 1: streaming (non-temporal) C stores; bit 1 (EPI = 1): also for g.  See g8_store_mode().
   int dbg;             // diagnostics (MRMT3_GEMM8_DBG): 1 no C stores, 2 plain instead of streaming C stores (bf16), 4 every K step re-reads K step 0 (cache-hot),
                        // 8 no fragment reads, 16 loads switched off (zero fill, no traffic)
   int skew_ticks;      // start delay per (slot % 8), in 10-ns ticks of s_memrealtime (see the kernel)
 };
+
+// C store mode (G8Params::nt_c), MRMT3_GEMM8_NT: bit 0 streaming C, bit 1 streaming g (fused wi + GEGLU launch).
+// Default 2: plain C stores.  Same-box, three alternations at 64 segments: 3 (both streaming, the round-2 state) 25.80 ms,
+// 1 25.77, 2 25.61, 0 25.63 — the consumer of C is the next kernel and finds it in the Infinity Cache.
+static int g8_store_mode() {
+  const char* e = getenv("MRMT3_GEMM8_NT");
+  return e ? atoi(e) & 3 : 2;
+}
 
 static int g8_cus() {
   static int n = 0;
@@ -331,8 +340,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
           bf16_t* hp = (bf16_t*)P.C + (size_t)row * P.ldc + f0;
           __builtin_nontemporal_store((u32x4{h0p[0], h0p[1], h0p[2], h0p[3]}), (u32x4*)hp);
           __builtin_nontemporal_store((u32x4{h1p[0], h1p[1], h1p[2], h1p[3]}), (u32x4*)(hp + P.dff));
-          __builtin_nontemporal_store((u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])}),
-                                      (u32x4*)((bf16_t*)P.C2 + (size_t)row * P.ldc2 + f0));
+          const u32x4 gv = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+          u32x4* gp = (u32x4*)((bf16_t*)P.C2 + (size_t)row * P.ldc2 + f0);
+          if (P.nt_c & 2) __builtin_nontemporal_store(gv, gp);      // (h: only the backward reads it again; g: the next kernel)
+          else *gp = gv;
         }
       }
       (void)count;
@@ -361,7 +372,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
         bf16_t* p = (bf16_t*)C + n0 + wc * 64 + (up ? 32 : 0) + fg * 8;
         // C is written once and not read by this kernel: streaming stores keep it from flushing the operand panels out
         // of the XCD's L2 (a round of 32 tiles is 4 MB, the whole L2)
-        if (P.dbg & 2) {
+        // The output of a product is read by the very next kernel (a norm, the attention, the GEGLU): plain stores leave
+        // it in the Infinity Cache.  Streaming stores made THIS kernel faster (the operand panels stay in the XCD's L2:
+        // a round of 32 tiles is 4 MB, the whole L2) but the step slower: 25.79 -> 25.58 ms with plain stores, three
+        // same-box alternations (MRMT3_GEMM8_NT=1 brings the streaming stores back).
+        if (!(P.nt_c & 1)) {
           if (row1 < P.M) *(u32x4*)(p + (size_t)row1 * P.ldc) = v1;
           if (row2 < P.M) *(u32x4*)(p + (size_t)row2 * P.ldc) = v2;
         } else {
@@ -519,6 +534,7 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
   P.A = (const bf16_t*)A; P.B = (const bf16_t*)B; P.C = C;
   P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K;
   P.ksplit = 1; P.mpad = 0; P.kfull = K;
+  P.nt_c = g8_store_mode();
   P.tiles_n = ceil_div(N, 256);
   const int cus = g8_cus() & ~7;
   const int tiles256 = ceil_div(M, 256) * P.tiles_n;
@@ -655,6 +671,7 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
   P.lda = ldx; P.ldb = ldw; P.ldc = ldh; P.ldc2 = ldg; P.dff = dff;
   P.M = rows; P.N = 2 * dff; P.K = K;
   P.ksplit = 1; P.mpad = 0; P.kfull = K;
+  P.nt_c = g8_store_mode();
   P.drop = make_drop(p_drop, seed, stream_id, step_dev);
   P.tiles_n = dff / 128;
   const int cus = g8_cus() & ~7;
