@@ -25,6 +25,31 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
   *(u32x2*)p = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
 }
 
+// streaming (non-temporal) forms: for operands a kernel reads once and nobody reads again soon (the saved activations of
+// the backward), and for outputs whose reader is several kernels away (the residual stream) — they then do not push
+// the tensors the NEXT kernel wants out of the 256 MB Infinity Cache
+template <typename T> __device__ __forceinline__ void load4_nt(const T* p, float v[4]);
+template <> __device__ __forceinline__ void load4_nt<float>(const float* p, float v[4]) {
+  const f32x4 t = __builtin_nontemporal_load((const f32x4*)p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4_nt<bf16_t>(const bf16_t* p, float v[4]) {
+  const u32x2 t = __builtin_nontemporal_load((const u32x2*)p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+}
+template <typename T> __device__ __forceinline__ void store4_nt(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4_nt<float>(float* p, const float v[4]) {
+  __builtin_nontemporal_store((f32x4{v[0], v[1], v[2], v[3]}), (f32x4*)p);
+}
+template <> __device__ __forceinline__ void store4_nt<bf16_t>(bf16_t* p, const float v[4]) {
+  __builtin_nontemporal_store((u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}), (u32x2*)p);
+}
+static inline int cache_mode_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused add + dropout + RMS norm, forward.   one wave per row, 4 rows per workgroup
 // HF T5LayerNorm: w * (x * rsqrt(mean(x^2) + eps)), fp32 statistics.
@@ -36,7 +61,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const float* __res
                                                               const float* __restrict__ w, float eps,
                                                               float* __restrict__ x1, TN* __restrict__ xn,
                                                               float* __restrict__ rstd_out, int rows, int cols,
-                                                              DropCfg dy, DropCfg dout, int out_drop) {
+                                                              DropCfg dy, DropCfg dout, int out_drop, int cache_mode) {
   DROP_STEP(dy); DROP_STEP(dout);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -49,7 +74,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const float* __res
   for (int i = 0; i < NV; ++i) {
     if (i < nv) {
       const int col = i * 256 + lane * 4;
-      load4<float>(x0 + base + col, v[i]);
+      if (cache_mode & 2) load4_nt<float>(x0 + base + col, v[i]);
+      else load4<float>(x0 + base + col, v[i]);
       if (y != nullptr) {
         float yv[4];
         load4<TY>(y + base + col, yv);
@@ -62,7 +88,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[i][e] += yv[e];
       }
-      if (x1 != nullptr) store4<float>(x1 + base + col, v[i]);
+      if (x1 != nullptr) {
+        if (cache_mode & 1) store4_nt<float>(x1 + base + col, v[i]);
+        else store4<float>(x1 + base + col, v[i]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
     }
@@ -99,9 +128,12 @@ extern "C" int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype
   DropCfg dy = make_drop(p_drop, seed, stream_y, step_dev), dn = make_drop(p_drop, seed, stream_out, step_dev);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // bit 0: streaming store of the residual stream x1 (its reader is the next norm, three kernels on), bit 1: streaming
+  // load of x0.  64 segments, same box, three alternations: 0 26.00 ms, 1 25.81, 2 25.97, 3 25.79 (MRMT3_NORM_NT)
+  const int cache_mode = cache_mode_env("MRMT3_NORM_NT", 3);
 #define LAUNCH2(TY, TN, NV)                                                                                 \
   hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<TY, TN, NV>), grid, block, 0, s, x0, (const TY*)y, w, eps, x1, \
-                     (TN*)xn, rstd, rows, cols, dy, dn, out_drop)
+                     (TN*)xn, rstd, rows, cols, dy, dn, out_drop, cache_mode)
 #define LAUNCH(TY, TN)                                                          \
   do {                                                                          \
     if (cols == 512) LAUNCH2(TY, TN, 2);                                        \
@@ -134,7 +166,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
                                                               const float* __restrict__ w, TRO* __restrict__ dx1,
                                                               bf16_t* __restrict__ dy, float* __restrict__ dw_part, int rows,
                                                               int cols, DropCfg ddy, DropCfg dout, int out_drop,
-                                                              int* __restrict__ dw_counters, int nb_rows_) {
+                                                              int* __restrict__ dw_counters, int nb_rows_, int cache_mode) {
   DROP_STEP(ddy); DROP_STEP(dout);
   __shared__ float red[4 * 256 * NV];  // [wave][col]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -158,7 +190,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
     if (dres != nullptr) {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
-        if (i < nv) load4<TRI>(dres + base + i * 256 + lane * 4, rr[i]);
+        if (i < nv) {
+          if (cache_mode & 4) load4_nt<TRI>(dres + base + i * 256 + lane * 4, rr[i]);
+          else load4<TRI>(dres + base + i * 256 + lane * 4, rr[i]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -171,7 +206,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
 #pragma unroll
           for (int e = 0; e < 4; ++e) g[i][e] *= m[e];
         }
-        load4<float>(x1 + base + col, xh[i]);
+        if (cache_mode & 1) load4_nt<float>(x1 + base + col, xh[i]);
+        else load4<float>(x1 + base + col, xh[i]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[i][e] *= rstd;
@@ -193,7 +229,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
 #pragma unroll
           for (int e = 0; e < 4; ++e) d[e] += rr[i][e];
         }
-        store4<TRO>(dx1 + base + col, d);
+        if (cache_mode & 2) store4_nt<TRO>(dx1 + base + col, d);
+        else store4<TRO>(dx1 + base + col, d);
         if (dy != nullptr) {
           if (ddy.thresh) {
             float m[4];
@@ -333,10 +370,14 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
   MR_CHECK_ARG(rows > 0 && (cols == 256 || cols == 512 || cols == 1024 || cols == 2048),
                "add_rmsnorm_bwd: cols must be 256, 512, 1024 or 2048");
   DropCfg dy = make_drop(p_drop, seed, stream_y, step_dev), dn = make_drop(p_drop, seed, stream_out, step_dev);
+  // bit 0: streaming load of x1 (the saved residual stream: read once), bit 1: streaming store of dx1 (the residual
+  // gradient: its reader is the next norm backward), bit 2: streaming load of dres (MRMT3_NORMB_NT).  Measured: none of
+  // them moves the 64-segment step (25.61-25.80 ms against 25.61-25.68, two alternations) — off.
+  const int cache_mode = cache_mode_env("MRMT3_NORMB_NT", 0);
 #define LAUNCH3(NV, TG, TRI, TRO)                                                                                 \
   hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG, TRI, TRO>), dim3((unsigned)ceil_div(rows, nbr)), dim3(256), 0, \
                      (hipStream_t)stream, (const TG*)dxn, (const TRI*)dres, x1, rstd, w, (TRO*)dx1, (bf16_t*)dy_bf16,  \
-                     dw_part, rows, cols, dy, dn, out_drop, dw_counters, nbr)
+                     dw_part, rows, cols, dy, dn, out_drop, dw_counters, nbr, cache_mode)
 #define LAUNCH2(NV, TG) LAUNCH3(NV, TG, float, float)
 #define LAUNCH(NV)                                       \
   do {                                                   \
@@ -413,7 +454,7 @@ __global__ void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ g, int
 
 template <typename T>
 __global__ void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dg, T* __restrict__ dh,
-                                 int rows, int dff, DropCfg d) {
+                                 int rows, int dff, DropCfg d, int cache_mode) {
   DROP_STEP(d);
   const size_t n8 = (size_t)rows * dff / 8;
   const int dff8 = dff / 8;
@@ -421,10 +462,17 @@ __global__ void geglu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ 
     const size_t row = i / dff8;
     const int col = (int)(i % dff8) * 8;
     float a[8], b[8], go[8], da[8], db[8];
-    load4<T>(h + row * 2 * dff + col, a);
-    load4<T>(h + row * 2 * dff + col + 4, a + 4);
-    load4<T>(h + row * 2 * dff + dff + col, b);
-    load4<T>(h + row * 2 * dff + dff + col + 4, b + 4);
+    if (cache_mode & 1) {                       // h: the saved projection, read once
+      load4_nt<T>(h + row * 2 * dff + col, a);
+      load4_nt<T>(h + row * 2 * dff + col + 4, a + 4);
+      load4_nt<T>(h + row * 2 * dff + dff + col, b);
+      load4_nt<T>(h + row * 2 * dff + dff + col + 4, b + 4);
+    } else {
+      load4<T>(h + row * 2 * dff + col, a);
+      load4<T>(h + row * 2 * dff + col + 4, a + 4);
+      load4<T>(h + row * 2 * dff + dff + col, b);
+      load4<T>(h + row * 2 * dff + dff + col + 4, b + 4);
+    }
     load4<T>(dg + row * dff + col, go);
     load4<T>(dg + row * dff + col + 4, go + 4);
     if (d.thresh) {
@@ -472,12 +520,13 @@ extern "C" int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows
                                uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(h && dg && dh && rows > 0 && dff % 8 == 0, "geglu_bwd: bad args");
   DropCfg d = make_drop(p_drop, seed, stream_id, step_dev);
+  const int cm = cache_mode_env("MRMT3_GEGLUB_NT", 0);      // bit 0: streaming load of h (measured: no change; off)
   if (dtype == MRMT3_F32)
     hipLaunchKernelGGL(geglu_bwd_kernel<float>, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)h, (const float*)dg, (float*)dh, rows, dff, d);
+                       (const float*)h, (const float*)dg, (float*)dh, rows, dff, d, cm);
   else
     hipLaunchKernelGGL(geglu_bwd_kernel<bf16_t>, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)h, (const bf16_t*)dg, (bf16_t*)dh, rows, dff, d);
+                       (const bf16_t*)h, (const bf16_t*)dg, (bf16_t*)dh, rows, dff, d, cm);
   MR_CHECK_LAUNCH("geglu_bwd");
   return MRMT3_OK;
 }
