@@ -283,13 +283,14 @@ int mrmt3_dropmask_cast(const float* dx, void* out, int out_dtype, size_t n, flo
  * normal target, (3,2) for an instrument token in [inst_lo,inst_hi] when weighted!=0 (the
  * reference's `sum_nonpad + 2*sum_inst` over `n_inst + n_nonpad`), (0,0) for ignored rows.
  * mrmt3_ce_count:   denom_dev[0] += sum_i n_i                      (zero it first)
- * mrmt3_ce_fwd_bwd: loss_dev[0]  += sum_i w_i * nll_i / denom      (zero it first)
+ * mrmt3_ce_fwd_bwd: loss_dev[0]  += sum_i w_i * nll_i / denom      (zero it first; a DOUBLE: one atomic add per
+ *                   workgroup in arrival order perturbs it at 1e-16, so the logged float is the same run after run)
  *                   dlogits (nullable, dl_dtype) = grad_scale * w_i * (softmax_i - onehot_i) / denom
  * Both scalars stay on the device: no host synchronisation. */
 int mrmt3_ce_count(const int64_t* targets, int rows, int weighted, int inst_lo, int inst_hi,
                    float* denom_dev, void* stream);
 int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* denom_dev,
-                     float* loss_dev, void* dlogits, int dl_dtype, int rows, int V, int weighted,
+                     double* loss_dev, void* dlogits, int dl_dtype, int rows, int V, int weighted,
                      int inst_lo, int inst_hi, float grad_scale, void* stream);
 
 /* lm_head + cross-entropy without the [rows][V] f32 logits in memory (models/t5.py:72,176-180 followed by
@@ -299,7 +300,7 @@ int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* d
  * accumulates, dlogits [rows][V] (dl_dtype; nullable: loss only) receives the gradient.  denom_dev as for
  * mrmt3_ce_fwd_bwd (run mrmt3_ce_count over ALL targets first; zero loss_dev first). */
 int mrmt3_lmhead_ce_fwd_bwd(const void* dec, int ld_dec, const void* W, int ldw, const int64_t* targets,
-                            const float* denom_dev, float* loss_dev, void* dlogits, int dl_dtype, int rows, int V,
+                            const float* denom_dev, double* loss_dev, void* dlogits, int dl_dtype, int rows, int V,
                             int d, int weighted, int inst_lo, int inst_hi, float grad_scale, void* workspace,
                             size_t workspace_bytes, int chunk_rows, void* stream);
 

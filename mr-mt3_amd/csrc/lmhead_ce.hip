@@ -7,11 +7,11 @@
 // (and, at 50-100 MB, stays in the 256 MB Infinity Cache), the loss kernel reads it there, adds the chunk's share of the
 // loss and leaves only the bf16 gradient w.r.t. the logits, which the two backward GEMMs of lm_head consume.
 // Arithmetic per row is exactly mrmt3_gemm_nt + mrmt3_ce_fwd_bwd (same kernels), so loss and gradients equal the unfused
-// path bit for bit except for the order in which the chunks' loss terms reach the (float-atomic) loss scalar.
+// path bit for bit; the loss scalar is accumulated in double (atomic adds in arrival order: 1e-16, invisible in the logged float).
 #include "common.h"
 
 extern "C" int mrmt3_lmhead_ce_fwd_bwd(const void* dec, int ld_dec, const void* W, int ldw, const int64_t* targets,
-                                       const float* denom_dev, float* loss_dev, void* dlogits, int dl_dtype, int rows,
+                                       const float* denom_dev, double* loss_dev, void* dlogits, int dl_dtype, int rows,
                                        int V, int d, int weighted, int inst_lo, int inst_hi, float grad_scale,
                                        void* workspace, size_t workspace_bytes, int chunk_rows, void* stream) {
   MR_CHECK_ARG(dec && W && targets && denom_dev && loss_dev && workspace, "lmhead_ce: null pointer");

@@ -890,7 +890,7 @@ extern "C" int mrmt3_ce_count(const int64_t* targets, int rows, int weighted, in
 
 template <typename TD>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
-                                                 const float* __restrict__ denom, float* __restrict__ loss,
+                                                 const float* __restrict__ denom, double* __restrict__ loss,
                                                  TD* __restrict__ dlogits, int rows, int V, int weighted, int lo,
                                                  int hi, float grad_scale) {
   __shared__ float red[8];
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   for (int w4 = 0; w4 < 4; ++w4) se += red[4 + w4] * expf(red[w4] - mx);
   const float lse = mx + logf(se);
   const float inv_den = 1.f / denom[0];
-  if (tid == 0) atomicAdd(loss, w * (lse - lp[t]) * inv_den);
+  if (tid == 0) atomicAdd(loss, (double)(w * (lse - lp[t]) * inv_den));
   if (dp) {
     const float gs = w * inv_den * grad_scale;
     for (int c = tid * 4; c < V; c += 1024) {
@@ -955,7 +955,7 @@ static inline int ce_rows_per_wave(int rows) {
 }
 template <typename TD, int NV>
 __global__ __launch_bounds__(256) void ce_wave_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
-                                                      const float* __restrict__ denom, float* __restrict__ loss,
+                                                      const float* __restrict__ denom, double* __restrict__ loss,
                                                       TD* __restrict__ dlogits, int rows, int weighted, int lo, int hi,
                                                       float grad_scale, int rpw) {
   constexpr int V = NV * 256;
@@ -1013,12 +1013,14 @@ __global__ __launch_bounds__(256) void ce_wave_kernel(const float* __restrict__ 
   if (lane == 0) part[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float tot = (part[0] + part[1]) + (part[2] + part[3]);
-    if (tot != 0.f) atomicAdd(loss, tot);
+    // the loss scalar is a DOUBLE: the order in which the workgroups' sums arrive perturbs it at 1e-16, far below the
+    // f32 value that is logged — two runs log the same float (a float accumulator wandered by a few ulp per run)
+    const double tot = ((double)part[0] + (double)part[1]) + ((double)part[2] + (double)part[3]);
+    if (tot != 0.0) atomicAdd(loss, tot);
   }
 }
 
-extern "C" int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* denom_dev, float* loss_dev,
+extern "C" int mrmt3_ce_fwd_bwd(const float* logits, const int64_t* targets, const float* denom_dev, double* loss_dev,
                                 void* dlogits, int dl_dtype, int rows, int V, int weighted, int inst_lo,
                                 int inst_hi, float grad_scale, void* stream) {
   MR_CHECK_ARG(logits && targets && denom_dev && loss_dev && rows > 0 && V % 4 == 0, "ce_fwd_bwd: bad args");

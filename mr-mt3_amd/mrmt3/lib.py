@@ -120,7 +120,7 @@ def load():
     return lib
 
 
-MIN_VERSION = 103
+MIN_VERSION = 104
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk")
 
@@ -730,15 +730,15 @@ def cross_entropy(logits, targets, want_grad=True, grad_dtype=torch.bfloat16, we
     """Returns (loss_dev[1] f32 tensor, dlogits or None).  No host sync."""
     _dev(logits, targets)
     rows, V = logits.shape
-    acc = torch.zeros(2, device=logits.device, dtype=torch.float32)  # [loss, denom]
+    acc = torch.zeros(2, device=logits.device, dtype=torch.float64)  # [loss (double accumulator), denom (f32 in its first 4 bytes)]
+    den = C.c_void_p(acc.data_ptr() + 8)
     lib = load()
-    _check(lib.mrmt3_ce_count(_p(targets), rows, int(weighted), inst_lo, inst_hi, C.c_void_p(acc.data_ptr() + 4),
-                              _stream()), "ce_count")
+    _check(lib.mrmt3_ce_count(_p(targets), rows, int(weighted), inst_lo, inst_hi, den, _stream()), "ce_count")
     dl = torch.empty(rows, V, device=logits.device, dtype=grad_dtype) if want_grad else None
-    _check(lib.mrmt3_ce_fwd_bwd(_p(logits), _p(targets), C.c_void_p(acc.data_ptr() + 4), _p(acc), _p(dl),
+    _check(lib.mrmt3_ce_fwd_bwd(_p(logits), _p(targets), den, _p(acc), _p(dl),
                                 _dt(dl) if dl is not None else F32, rows, V, int(weighted), inst_lo, inst_hi,
                                 grad_scale, _stream()), "ce_fwd_bwd")
-    return acc[0:1], dl
+    return acc[0:1].float(), dl
 
 
 def lmhead_cross_entropy(dec, w, targets, want_grad=True, grad_dtype=torch.bfloat16, weighted=False, inst_lo=1135,
@@ -749,17 +749,17 @@ def lmhead_cross_entropy(dec, w, targets, want_grad=True, grad_dtype=torch.bfloa
     rows, d = dec.shape
     V = w.shape[0]
     assert dec.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and dec.stride(1) == 1 and w.stride(1) == 1
-    acc = torch.zeros(2, device=dec.device, dtype=torch.float32)  # [loss, denom]
+    acc = torch.zeros(2, device=dec.device, dtype=torch.float64)  # [loss (double accumulator), denom (f32 in its first 4 bytes)]
+    den = C.c_void_p(acc.data_ptr() + 8)
     lib = load()
-    _check(lib.mrmt3_ce_count(_p(targets), rows, int(weighted), inst_lo, inst_hi, C.c_void_p(acc.data_ptr() + 4),
-                              _stream()), "ce_count")
+    _check(lib.mrmt3_ce_count(_p(targets), rows, int(weighted), inst_lo, inst_hi, den, _stream()), "ce_count")
     dl = torch.empty(rows, V, device=dec.device, dtype=grad_dtype) if want_grad else None
     ws = workspace(min(rows, chunk_rows) * V * 4, dec.device)
     _check(lib.mrmt3_lmhead_ce_fwd_bwd(_p(dec), dec.stride(0), _p(w), w.stride(0), _p(targets),
-                                       C.c_void_p(acc.data_ptr() + 4), _p(acc), _p(dl), _dt(dl) if dl is not None else F32,
+                                       den, _p(acc), _p(dl), _dt(dl) if dl is not None else F32,
                                        rows, V, d, int(weighted), inst_lo, inst_hi, grad_scale, _p(ws), ws.numel(),
                                        chunk_rows, _stream()), "lmhead_ce_fwd_bwd")
-    return acc[0:1], dl
+    return acc[0:1].float(), dl
 
 
 def adamw_step(p, g, m, v, lr_dev, step_dev, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0,

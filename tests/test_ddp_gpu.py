@@ -104,7 +104,7 @@ def test_two_ranks_segmented_graph_replay_equals_eager():
     assert torch.cuda.is_available()
 
     def same(a, b):
-        return all(r0 == r1 and np.array_equal(g0, g1) and np.array_equal(p0, p1) and abs(l0 - l1) < 1e-5
+        return all(r0 == r1 and np.array_equal(g0, g1) and np.array_equal(p0, p1) and abs(l0 - l1) < 2e-6
                    for (r0, g0, p0, l0), (r1, g1, p1, l1) in zip(a, b))
     eager = _run_two_ranks(steps=5, graph=False)
     graph = _run_two_ranks(steps=5, graph=True)

@@ -247,7 +247,7 @@ def test_fp32_training_with_dropout_draws_the_bf16_masks_and_replays_from_graphs
     d = np.abs(np.array(runs["f32"][0]) - np.array(runs["bf16"][0]))
     assert d[:3].max() < 5e-3 and d.max() < 3e-2, (runs["f32"][0], runs["bf16"][0])
     assert runs["f32"][0][-1] < runs["f32"][0][1]                       # it trains (step 0 is before the first update)
-    assert np.allclose(runs["f32"][0], runs["f32_graph"][0], rtol=0, atol=1e-5)
+    assert np.allclose(runs["f32"][0], runs["f32_graph"][0], rtol=0, atol=2e-6)
     assert torch.equal(runs["f32"][1], runs["f32_graph"][1])
 
 

@@ -66,10 +66,9 @@ def test_graph_replay_is_bitwise_the_eager_trajectory(dev, variant):
         assert int(tr.step_dev.item()) == 20
         runs[use_graph] = ([float(x.item()) for x in losses], m.flat.P.clone(), m.flat.M.clone(), m.flat.V.clone())
     le, lg = runs[False][0], runs[True][0]
-    # (the logged loss scalar is the one float-atomically accumulated value of a step — one atomicAdd per workgroup of
-    # the cross-entropy kernel, hundreds of them in arrival order: differences of a few ulp (5e-7 each at 7.x) between
-    # any two runs, eager or not; nothing is computed from it)
-    assert np.allclose(le, lg, rtol=0, atol=1e-5), list(zip(le, lg))
+    # (the logged loss scalar is the one atomically accumulated value of a step — one atomic add per workgroup of the
+    # cross-entropy kernel, in arrival order, into a DOUBLE: the float that is logged comes out the same run after run)
+    assert np.allclose(le, lg, rtol=0, atol=2e-6), list(zip(le, lg))
     assert le[-1] < le[0]                                     # and it is a real training run
     for a, b in zip(runs[False][1:], runs[True][1:]):
         assert torch.equal(a, b)
@@ -85,13 +84,13 @@ def test_masks_change_from_step_to_step_under_replay(dev):
     for use_graph in (False, True):
         tr = Trainer(_model("t5", dev), lr=0.0, graph=use_graph)
         got[use_graph] = [float(tr.train_step(a, t, audio=True).item()) for _ in range(7)]
-    assert np.allclose(got[True], got[False], rtol=0, atol=1e-5)
+    assert np.allclose(got[True], got[False], rtol=0, atol=2e-6)
     replayed = got[True][2:]                                   # steps 0-1 are the eager warm-up, 2.. come from the graph
     assert min(abs(x - y) for i, x in enumerate(replayed) for y in replayed[i + 1:]) > 1e-4, replayed
     # dropout off: every step identical (the only other source of variation would be a bug)
     tr = Trainer(_model("t5", dev, dropout_rate=0.0), lr=0.0, graph=True)
     same = [float(tr.train_step(a, t, audio=True).item()) for _ in range(5)]
-    assert max(same) - min(same) < 1e-5, same
+    assert max(same) - min(same) < 2e-6, same
 
 
 def test_graph_follows_new_inputs_weights_and_shapes(dev):
@@ -103,14 +102,14 @@ def test_graph_follows_new_inputs_weights_and_shapes(dev):
     tr = Trainer(m, lr=0.0, graph=True)
     base = [float(tr.train_step(a, t, audio=True).item()) for a, t, _ in data]          # 2 eager + capture + replay
     again = [float(tr.train_step(a, t, audio=True).item()) for a, t, _ in data]         # all replays
-    assert np.allclose(base, again, rtol=0, atol=1e-5) and min(abs(x - y) for i, x in enumerate(base) for y in base[i + 1:]) > 1e-4
+    assert np.allclose(base, again, rtol=0, atol=2e-6) and min(abs(x - y) for i, x in enumerate(base) for y in base[i + 1:]) > 1e-4
     sd = {k: (v * 0.5 if v.dim() == 2 else v.clone()) for k, v in m.state_dict().items()}
     m.load_state_dict(sd)
     changed = float(tr.train_step(*data[0][:2], audio=True).item())
     assert abs(changed - base[0]) > 1e-3
     a, t, _ = _batches(dev, 1, B=2, L=128)[0]
     l1 = [float(tr.train_step(a, t, audio=True).item()) for _ in range(4)]
-    assert len(tr._graphs) == 2 and max(l1) - min(l1) < 1e-5
+    assert len(tr._graphs) == 2 and max(l1) - min(l1) < 2e-6
 
 
 def test_host_issue_time_of_a_replayed_step(dev):
@@ -155,7 +154,7 @@ def test_a_failed_capture_falls_back_to_eager_steps(dev, monkeypatch):
         warnings.simplefilter("always")
         got = [float(tr.train_step(a, t, audio=True).item()) for _ in range(5)]
     assert any("capture" in str(x.message) for x in w) and not tr.use_graph and not tr.graph_captured
-    assert np.allclose(got, want, rtol=0, atol=1e-5), (got, want)
+    assert np.allclose(got, want, rtol=0, atol=2e-6), (got, want)
 
 
 def test_bucketed_step_with_grouped_weight_gradients_captures_and_equals_eager(dev, monkeypatch):
@@ -188,7 +187,7 @@ def test_bucketed_step_with_grouped_weight_gradients_captures_and_equals_eager(d
                 assert len(cap.segments) == len(tr.buckets.buckets)
                 assert tr.engine.tn_group is not None and sum(e["captured"] for e in tr.engine.tn_group._plans.values()) >= 6
             runs[use_graph] = (losses, m.flat.P.clone(), m.flat.M.clone())
-        assert np.allclose(runs[False][0], runs[True][0], rtol=0, atol=1e-5)
+        assert np.allclose(runs[False][0], runs[True][0], rtol=0, atol=2e-6)
         assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])
     finally:
         dist.destroy_process_group()
