@@ -742,13 +742,17 @@ def cross_entropy(logits, targets, want_grad=True, grad_dtype=torch.bfloat16, we
 
 
 def lmhead_cross_entropy(dec, w, targets, want_grad=True, grad_dtype=torch.bfloat16, weighted=False, inst_lo=1135,
-                         inst_hi=1262, grad_scale=1.0, chunk_rows=16384):
+                         inst_hi=1262, grad_scale=1.0, chunk_rows=None):
     """lm_head + CE fused over row chunks (mrmt3_lmhead_ce_fwd_bwd): dec [rows, d] bf16, w [V, d] bf16 ->
     (loss_dev[1] f32, dlogits [rows, V] or None).  The f32 logits only ever exist one chunk at a time, in a workspace."""
     _dev(dec, w, targets)
     rows, d = dec.shape
     V = w.shape[0]
     assert dec.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and dec.stride(1) == 1 and w.stride(1) == 1
+    if chunk_rows is None:
+        # 65 536 rows = 403 MB of f32 logits in the workspace: the 64-segment step in ONE chunk (25.41 -> 25.32 ms against
+        # four chunks of 16 384, same box); larger batches still go chunk by chunk (MRMT3_CE_CHUNK)
+        chunk_rows = int(os.environ.get("MRMT3_CE_CHUNK", "65536"))
     acc = torch.zeros(2, device=dec.device, dtype=torch.float64)  # [loss (double accumulator), denom (f32 in its first 4 bytes)]
     den = C.c_void_p(acc.data_ptr() + 8)
     lib = load()
