@@ -193,3 +193,28 @@ def test_grouped_weight_gradient_plan_covers_every_tile_once():
     for i in range(info.n_items):
         assert shelf_cnt[int(items["sync_idx"][i])] == items["sync_n"][i]
     assert not host[info.sync_offset:info.sync_offset + 4 * len(shelf_cnt)].any()          # the arrival counters start at zero
+
+
+def test_host_side_dispatch_rules_without_a_gpu():
+    """The planners that decide which kernel a shape runs on are host code (no launch): pinned here for the shapes of
+    the step at 64 and 12 segments per GPU (a box without a GPU reports 256 CUs, the MI355X's count)."""
+    L = lib.load()
+    BF16 = 1
+    # split K (mrmt3_gemm_nt_ws): only short inputs with K >= 2048 and >= 512 per split
+    mpad = lambda m: -(-m // 128) * 128
+    assert L.mrmt3_gemm_nt_workspace_bytes(3072, 512, 2048, BF16) == 4 * mpad(3072) * 512 * 4       # encoder d_wi, 12 segments
+    assert L.mrmt3_gemm_nt_workspace_bytes(3072, 512, 6144, BF16) == 4 * mpad(3072) * 512 * 4       # cross k|v gradient
+    assert L.mrmt3_gemm_nt_workspace_bytes(3000, 512, 2048, BF16) == 4 * mpad(3000) * 512 * 4       # ragged rows: padded slabs
+    for shape in ((3072, 512, 1024), (3072, 512, 1152), (16384, 512, 2048), (65536, 512, 2048), (3072, 136, 2048),
+                  (512, 512, 4096)):
+        assert L.mrmt3_gemm_nt_workspace_bytes(*shape, BF16) == 0, shape
+    assert L.mrmt3_gemm_nt_workspace_bytes(3072, 512, 2048, 0) == 0                                  # f32 operands: never
+    # grouped weight gradients: widths on the 128 / 64 grid only (tests/test_fuzz_gpu.py found 576 admitted once)
+    assert L.mrmt3_tn_group_ok(65536, 1152, 512, 1152, 512, 512) == 1
+    assert L.mrmt3_tn_group_ok(65536, 576, 512, 576, 512, 512) == 0
+    assert L.mrmt3_tn_group_ok(65536, 512, 520, 512, 520, 520) == 0
+    assert L.mrmt3_tn_group_ok(512, 512, 512, 512, 512, 512) == 0                                    # too few token rows
+    # scratch of the one-by-one weight gradient and of the norm backward are pure functions of the shape
+    assert L.mrmt3_gemm_tn_workspace_bytes(65536, 2048, 512) == L.mrmt3_gemm_tn_splits(65536, 2048, 512) * 2048 * 512 * 4
+    assert L.mrmt3_add_rmsnorm_bwd_workspace_bytes(65536, 512) > L.mrmt3_add_rmsnorm_bwd_partial_rows(65536) * 512 * 4
+    assert L.mrmt3_add_rmsnorm_bwd_partial_rows(12288) >= 2048                                       # short inputs: >= ~2048 workgroups
