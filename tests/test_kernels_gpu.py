@@ -865,7 +865,7 @@ def test_transpose_batched_even_and_odd_shapes(dev):
     fallback (odd dims or offsets), tiles that overhang the matrix."""
     import numpy as np
     from mrmt3 import lib
-    shapes = [(384, 512), (70, 130), (33, 7), (64, 64), (5, 1000)]
+    shapes = [(384, 512), (70, 130), (33, 7), (64, 64), (5, 1000), (136, 72), (2048, 512), (72, 200)]   # (multiples of 8: the 16-byte path inside, the scalar path on overhanging tiles)
     src_parts, recs, starts, tot, so, do = [], [], [], 0, 0, 0
     for r, c in shapes:
         src_parts.append(torch.randn(r * c, device=dev).bfloat16())
