@@ -267,6 +267,35 @@ def inference_rtf(dev, tokens, batch):
     return out
 
 
+PMC_TABLES = ("r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json")
+
+
+def pmc_table(batch, lib_version):
+    """The newest committed whole-step PMC table (bytes per family and per step) that was measured on this library
+    version and at this batch size: (table, name, None), else (None, None, reason).  Tables carry `lib_version` and
+    `batch` stamps (r03's has none: it is version 104 at 64 segments); a stale table must not ride along in a bench
+    line (VERDICT r3 #7, ADVICE r3)."""
+    why = []
+    for name in PMC_TABLES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as fh:
+                tab = json.load(fh)
+        except Exception as e:
+            why.append("%s unreadable (%s)" % (name, e))
+            continue
+        tv, tb = int(tab.get("lib_version", 104)), int(tab.get("batch", 64))
+        if tv != lib_version:
+            why.append("%s was measured on library version %d, this is %d" % (name, tv, lib_version))
+        elif tb != batch:
+            why.append("%s is a %d-segment table, this run has %d" % (name, tb, batch))
+        else:
+            return tab, "profiles/" + name, None
+    return None, None, "no PMC table for this run: " + ("; ".join(why) if why else "none committed")
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 while the bench
@@ -380,22 +409,20 @@ def main():
         f = fam[dom]
         # HBM traffic of the dominant family: rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction
         # of MI355X_MICROARCH.md) cannot run inside this process; the whole-step table they produced for this tree is
-        # committed (profiles/r03_pmc_step_traffic.json, made by profiles/tools/pmc_step_traffic.sh) and folded in here.
+        # committed (profiles/r0N_pmc_step_traffic.json, made by profiles/tools/pmc_step_traffic.sh) and folded in here —
+        # only when the table was measured on THIS library version and at THIS batch (pmc_table() says why not otherwise).
+        from mrmt3 import lib as _lib
+        tab, tab_name, tab_note = pmc_table(B, _lib.load().mrmt3_version())
         traffic = None
-        try:
-            # measured: the family's row of the whole-step PMC table (profiles/r03_pmc_step_traffic.json: 2 x FETCH_SIZE +
-            # WRITE_SIZE over one eager step, separate passes); algorithmic: operands once + output once, summed over
-            # this run's launches of the family
-            from mrmt3 import lib as _lib
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json")) as fh:
-                fam_tab = json.load(fh)["families"]["gemm_nt"]
+        if tab is not None and "gemm_nt" in tab.get("families", {}):
+            # measured: the family's row of the whole-step PMC table (2 x FETCH_SIZE + WRITE_SIZE over one eager step,
+            # separate passes); algorithmic: operands once + output once, summed over this run's launches of the family
+            fam_tab = tab["families"]["gemm_nt"]
             meas = (fam_tab["read_bytes"] + fam_tab["write_bytes"]) / fam_tab["launches"]
             alg = _lib.PROFILE_BYTES.get(dom, 0.0) / max(f["n"], 1)
             traffic = {"bytes_per_launch": meas, "algorithmic_bytes_per_launch": alg, "ratio": meas / alg if alg else None,
-                       "source": "profiles/r03_pmc_step_traffic.json (B = 64 table: %d launches of the family per step incl. "
-                                 "the lm_head chunks launched inside mrmt3_lmhead_ce_fwd_bwd)" % fam_tab["launches"]}
-        except Exception:
-            pass
+                       "source": "%s (%d launches of the family per step incl. the lm_head chunks launched inside "
+                                 "mrmt3_lmhead_ce_fwd_bwd)" % (tab_name, fam_tab["launches"])}
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": rate(f), "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": rate(f) / PEAK_BF16_TFLOPS, "traffic": traffic,
                            "launches": f["n"], "avg_launch_ms": f["ms"] / f["n"],
@@ -410,17 +437,16 @@ def main():
                            "families_achieved": {k: rate(v) for k, v in fam.items()}}
         # HBM side of the whole step: bytes per step from the committed whole-step PMC table (profiles/tools/
         # pmc_step_traffic.sh) over this run's step time, next to the MFMA fraction (the step holds 14.4 TFLOP)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json")) as fh:
-                st = json.load(fh)
-            step_s = dt / args.steps
-            res["roofline"]["step"] = {"step_bytes": st["step_bytes"], "hbm_GBps": st["step_bytes"] / step_s / 1e9,
-                                       "hbm_frac": st["step_bytes"] / step_s / 1e9 / PEAK_HBM_GBS,
-                                       "mfma_TFLOPs": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12,
-                                       "mfma_frac": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12 / PEAK_BF16_TFLOPS,
-                                       "source": "profiles/r03_pmc_step_traffic.json (B = 64 table; valid for --batch 64)"}
-        except Exception:
-            pass
+        step_s = dt / args.steps
+        res["roofline"]["step"] = {"mfma_TFLOPs": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12,
+                                   "mfma_frac": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12 / PEAK_BF16_TFLOPS}
+        if tab is not None:
+            res["roofline"]["step"].update({"step_bytes": tab["step_bytes"], "hbm_GBps": tab["step_bytes"] / step_s / 1e9,
+                                            "hbm_frac": tab["step_bytes"] / step_s / 1e9 / PEAK_HBM_GBS, "source": tab_name})
+        else:
+            res["roofline"]["step"].update({"step_bytes": None, "hbm_GBps": None, "hbm_frac": None, "source": tab_note})
+        if traffic is None:
+            res["roofline"]["traffic_note"] = tab_note
     sync()
     if rank == 0 and not args.no_inference:
         del trainer, model

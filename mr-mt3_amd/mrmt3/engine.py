@@ -80,6 +80,8 @@ class Engine:
         self.norm_dw = lib.NormDwBatch() if os.environ.get("MRMT3_NORM_DW_BATCH", "1") != "0" else None
         # split-K slabs of the weight-gradient GEMMs: kept per site and summed in one launch (lib.TnBatch)
         self.tn_batch = lib.TnBatch() if os.environ.get("MRMT3_TN_BATCH", "1") != "0" else None
+        if self.tn_batch is not None:
+            self.tn_batch.before_early_flush = self._join_side
         # ... and, for every shape the grouped kernel takes, the GEMMs themselves are deferred to the next join_wgrad():
         # one launch for the weight gradients of a whole gradient bucket (lib.TnGroup)
         self.tn_group = lib.TnGroup() if os.environ.get("MRMT3_TN_GROUP", "1") != "0" else None
@@ -162,10 +164,8 @@ class Engine:
         if self.norm_dw is not None:
             self.norm_dw.flush()
 
-    def join_wgrad(self):
-        """Make the current stream wait for every weight gradient issued so far (and sum the queued norm-weight
-        gradients: both are what a gradient bucket needs before it is sent)."""
-        self.flush_norm_dw()
+    def _join_side(self):
+        """The current stream waits for the side stream's weight-gradient launches issued so far."""
         if self.overlap_wgrad and self._side is not None and self._side_dirty:
             # (only when the side stream has work since the last join: under graph capture a wait on a stream that
             # is not part of the capture would tie the graph to uncaptured work)
@@ -173,6 +173,12 @@ class Engine:
             torch.cuda.current_stream().wait_stream(self._side)
             # operands may be recycled now: whatever the current stream does next runs after the side work
             self._held.clear()
+
+    def join_wgrad(self):
+        """Make the current stream wait for every weight gradient issued so far (and sum the queued norm-weight
+        gradients: both are what a gradient bucket needs before it is sent)."""
+        self.flush_norm_dw()
+        self._join_side()
         if self.tn_batch is not None:
             self.tn_batch.flush()        # behind the GEMMs that produced the slabs (same stream, or joined above)
         if self.tn_group is not None:

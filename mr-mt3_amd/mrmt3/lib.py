@@ -289,11 +289,18 @@ class TnBatch:
         self._slabs = {}       # (out address, M, N1, N2) -> slab tensor
         self._queue = []       # [(key, out, ldc, accumulate)]
         self._tables = {}
+        # called before a flush that site() triggers by itself (the same gradient queued twice): the partial GEMMs of
+        # the queued sites may have been launched on another stream (Engine.wgrad's side stream), which the CURRENT
+        # stream — where the flush's reduce runs — has not joined yet.  The engine sets it to its join.
+        self.before_early_flush = None
 
     def site(self, out, M, N1, N2, accumulate):
         key = (out.data_ptr(), M, N1, N2, out.stride(0), int(accumulate))
         if key in self._queue:
-            self.flush()               # the same gradient twice before a flush: its slab buffer is still waiting to be summed
+            # the same gradient twice before a flush: its slab buffer is still waiting to be summed
+            if self.before_early_flush is not None:
+                self.before_early_flush()
+            self.flush()
         buf = self._slabs.get(key)
         if buf is None:
             buf = torch.empty(load().mrmt3_gemm_tn_workspace_bytes(M, N1, N2), device=out.device, dtype=torch.uint8)
@@ -741,6 +748,18 @@ def cross_entropy(logits, targets, want_grad=True, grad_dtype=torch.bfloat16, we
     return acc[0:1].float(), dl
 
 
+def ce_chunk_rows() -> int:
+    """MRMT3_CE_CHUNK (rows of logits per lm_head + CE chunk), validated: an integer, at least 1024."""
+    raw = os.environ.get("MRMT3_CE_CHUNK", "65536")
+    try:
+        n = int(raw)
+    except ValueError:
+        raise ValueError(f"MRMT3_CE_CHUNK={raw!r} is not an integer") from None
+    if n < 1024:
+        raise ValueError(f"MRMT3_CE_CHUNK={n}: a chunk is at least 1024 rows")
+    return n
+
+
 def lmhead_cross_entropy(dec, w, targets, want_grad=True, grad_dtype=torch.bfloat16, weighted=False, inst_lo=1135,
                          inst_hi=1262, grad_scale=1.0, chunk_rows=None):
     """lm_head + CE fused over row chunks (mrmt3_lmhead_ce_fwd_bwd): dec [rows, d] bf16, w [V, d] bf16 ->
@@ -752,7 +771,7 @@ def lmhead_cross_entropy(dec, w, targets, want_grad=True, grad_dtype=torch.bfloa
     if chunk_rows is None:
         # 65 536 rows = 403 MB of f32 logits in the workspace: the 64-segment step in ONE chunk (25.41 -> 25.32 ms against
         # four chunks of 16 384, same box); larger batches still go chunk by chunk (MRMT3_CE_CHUNK)
-        chunk_rows = int(os.environ.get("MRMT3_CE_CHUNK", "65536"))
+        chunk_rows = ce_chunk_rows()
     acc = torch.zeros(2, device=dec.device, dtype=torch.float64)  # [loss (double accumulator), denom (f32 in its first 4 bytes)]
     den = C.c_void_p(acc.data_ptr() + 8)
     lib = load()

@@ -81,14 +81,26 @@ def real_loaders(cfg, world=1, rank=0):
     return (DataLoader(train_set, collate_fn=collate, **kw_t), DataLoader(val_set, collate_fn=collate, **kw_v), sampler)
 
 
-def loader_batches(loader, device, epochs, max_steps, start_epoch=0, start_step=0, sampler=None):
+def resume_position(global_step, steps_per_epoch):
+    """(epoch, batches of that epoch already consumed) for a run that has taken `global_step` optimizer steps.  The
+    position is derived from the step count alone: a checkpoint's `epoch` field is the epoch in progress OR the one
+    just completed depending on when it was written, the step count is unambiguous."""
+    if steps_per_epoch <= 0:
+        return 0, 0
+    return global_step // steps_per_epoch, global_step % steps_per_epoch
+
+
+def loader_batches(loader, device, epochs, max_steps, start_epoch=0, start_step=0, sampler=None, skip=0):
     """(epoch, inputs, targets, targets_prev) from the reference's collated batches, moved to the device.  A resumed
-    run continues at (start_epoch, start_step): `max_steps` counts global steps, like Lightning's."""
+    run continues at (start_epoch, start_step) and drops the first `skip` batches of that epoch (the ones the
+    interrupted run consumed): `max_steps` counts global steps, like Lightning's."""
     n = start_step
     for ep in range(start_epoch, epochs):
         if sampler is not None:
             sampler.set_epoch(ep)            # a different shuffle per epoch, the same one on every rank
-        for batch in loader:
+        for bi, batch in enumerate(loader):
+            if ep == start_epoch and bi < skip:
+                continue
             if max_steps is not None and n >= max_steps:
                 return
             inputs, targets = batch[0], batch[1]
@@ -132,16 +144,16 @@ def main(argv=None):
     train_loader = val_loader = sampler = None
     if not synthetic:
         train_loader, val_loader, sampler = real_loaders(cfg, world, rank)
-    start, start_epoch, resumed = 0, 0, False
+    start, start_epoch, skip, resumed = 0, 0, 0, False
     path = cfg.get("path")
     if path is not None and str(path) != "":
         path = str(path)
         if path.endswith(".ckpt"):
             start = trainer.resume(path)
-            from mrmt3 import checkpoint as ck
-            start_epoch = int(ck.read_checkpoint(path).get("epoch", 0) or 0)
+            if train_loader is not None:
+                start_epoch, skip = resume_position(start, len(train_loader))
             if rank == 0:
-                print(f"Resuming from {path} at step {start}, epoch {start_epoch}", flush=True)
+                print(f"Resuming from {path} at step {start}, epoch {start_epoch} (+{skip} batches)", flush=True)
         elif path.endswith(".pth"):
             if rank == 0:
                 print(f"Loading weights from {path}...", flush=True)
@@ -178,7 +190,7 @@ def main(argv=None):
         if resumed:
             validate(start_epoch)        # the reference validates the loaded weights before fit (train.py:61-87)
         for ep, mel, labels, prev in loader_batches(train_loader, device, int(cfg.num_epochs), max_steps,
-                                                    start_epoch, start, sampler):
+                                                    start_epoch, start, sampler, skip):
             if ep != last_ep and (last_ep + 1) % val_every == 0:
                 validate(last_ep)
             last_ep = ep
@@ -194,7 +206,7 @@ def main(argv=None):
         out_dir = os.path.join(str(cfg.get("output_dir", ".")), f"{cfg.model_type}_{cfg.dataset_type}",
                                "version_0", "checkpoints")
         os.makedirs(out_dir, exist_ok=True)
-        trainer.save_checkpoint(os.path.join(out_dir, "last.ckpt"))
+        trainer.save_checkpoint(os.path.join(out_dir, "last.ckpt"), epoch=0 if synthetic else last_ep)
         trainer.save_checkpoint(os.path.join(out_dir, "last.pt"))
         print(f"Saved model in {os.path.join(out_dir, 'last.pt')}.", flush=True)
     if world > 1:

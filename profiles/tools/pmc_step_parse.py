@@ -2,14 +2,17 @@
 (FETCH_SIZE, WRITE_SIZE; separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"):
     bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024     (KB units; gfx950 tallies 128-byte fetches at 64: x2)
 The last step of each pass is cut out between two adamw_kernel dispatches.
-    python3 profiles/tools/pmc_step_parse.py <fetch dir> <write dir> <out.txt> [<out.json>]"""
+    python3 profiles/tools/pmc_step_parse.py <fetch dir> <write dir> <out.txt> [<out.json> [<lib version> [<batch>]]]
+The JSON table is stamped with the library version and the batch it was measured on: bench.py folds it into its line
+only when both match the run (a stale table must not ride along)."""
 import csv
 import glob
 import json
 import os
 import sys
 
-FAMILIES = (("gemm_nt8_kernel<unsigned short, false, 8, 1>", "gemm_nt_geglu"), ("gemm_nt8_kernel<unsigned short, false, 4, 1>", "gemm_nt_geglu"),
+FAMILIES = (("gemm_rows_kernel<0", "gemm_nt_addnorm"), ("gemm_rows_kernel<1", "gemm_nt_normbwd"), ("gemm_rows_kernel<2", "gemm_nt_geglubwd"),
+            ("gemm_nt8_kernel<unsigned short, false, 8, 1>", "gemm_nt_geglu"), ("gemm_nt8_kernel<unsigned short, false, 4, 1>", "gemm_nt_geglu"),
             ("gemm_nt8", "gemm_nt"), ("gemm_nt_kernel", "gemm_nt"), ("gemm_tn8_group", "gemm_tn_group"), ("tn8_group_reduce", "gemm_tn_group"),
             ("gemm_tn", "gemm_tn_other"), ("slab_reduce", "gemm_tn_other"), ("attn_fwd", "attn_fwd"), ("attn_bwd", "attn_bwd"),
             ("add_rmsnorm_fwd", "norm_fwd"), ("add_rmsnorm_bwd", "norm_bwd"), ("dw_reduce", "norm_bwd"), ("geglu_bwd", "geglu_bwd"),
@@ -57,5 +60,6 @@ print("\n".join(lines))
 if len(sys.argv) > 4:
     json.dump({"step_bytes": tot_r + tot_w, "read_bytes": tot_r, "write_bytes": tot_w, "kernels": len(fe),
                "families": {k: {"launches": v[2], "read_bytes": v[0], "write_bytes": v[1]} for k, v in fam.items()},
+               "lib_version": int(sys.argv[5]) if len(sys.argv) > 5 else None, "batch": int(sys.argv[6]) if len(sys.argv) > 6 else 64,
                "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over profiles/tools/pmc_step.py, last step; bytes = 2 x FETCH + WRITE"},
               open(sys.argv[4], "w"), indent=1)

@@ -62,3 +62,24 @@ def test_loader_batches_counts_global_steps_and_resumes_mid_run(tmp_path):
     # resumed at global step 3 in epoch 1 with max_steps = 5: two more steps, all in epoch 1
     resumed = list(train.loader_batches(tl, dev, epochs=2, max_steps=5, start_epoch=1, start_step=3))
     assert [b[0] for b in resumed] == [1, 1]
+
+
+def test_resume_position_from_the_step_count_never_overshoots_the_schedule(tmp_path):
+    """a run resumed from its own last.ckpt must continue where it stopped — epoch and batch offset derived from
+    the global step — and take exactly the remaining steps of num_epochs x steps_per_epoch, whether the checkpoint was
+    written mid-epoch or at an epoch's end."""
+    import train
+    cfg = _cfg(tmp_path, n_train=6)
+    tl, _, _ = train.real_loaders(cfg)                            # 3 batches per epoch
+    dev = torch.device("cpu")
+    spe, epochs = len(tl), 3
+    assert spe == 3
+    assert train.resume_position(0, spe) == (0, 0)
+    assert train.resume_position(4, spe) == (1, 1)                # mid-epoch: one batch of epoch 1 already consumed
+    assert train.resume_position(6, spe) == (2, 0)                # end of epoch 1: continue with epoch 2, nothing skipped
+    assert train.resume_position(9, spe) == (3, 0)                # the schedule is finished: no epoch left
+    for done in range(0, spe * epochs + 1):
+        ep0, skip = train.resume_position(done, spe)
+        rest = list(train.loader_batches(tl, dev, epochs=epochs, max_steps=None, start_epoch=ep0, start_step=done, skip=skip))
+        assert done + len(rest) == spe * epochs, (done, len(rest))
+        assert [b[0] for b in rest] == [e for e in range(epochs) for _ in range(spe)][done:]
