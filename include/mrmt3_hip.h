@@ -66,7 +66,10 @@ void mrmt3_host_free(void* p);
 #define MRMT3_CNT_ATTN_F32 9          /* exact-f32 attention kernels */
 #define MRMT3_CNT_TN_F32 10           /* exact-f32 weight-gradient kernel */
 #define MRMT3_CNT_GEMM_NT_SPLITK 11   /* ping-pong NT kernel split over K + reduce (mrmt3_gemm_nt_ws, short inputs) */
-#define MRMT3_CNT_N 12
+#define MRMT3_CNT_GEMM_NT_ADDNORM 12  /* projection + residual add + RMS norm in one launch (mrmt3_gemm_nt_addnorm) */
+#define MRMT3_CNT_GEMM_NT_NORMBWD 13  /* data gradient + norm backward in one launch (mrmt3_gemm_nt_normbwd) */
+#define MRMT3_CNT_GEMM_NT_GEGLUBWD 14 /* wo data gradient + gated-GELU backward in one launch (mrmt3_gemm_nt_geglubwd) */
+#define MRMT3_CNT_N 15
 int mrmt3_dispatch_counts(unsigned long long* out, int n, int reset);
 
 /* ---- K1: log-mel frontend ---------------------------------------------------------------------
@@ -252,6 +255,40 @@ int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows, int dff, 
 int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int ldw, void* h, int ldh, void* g, int ldg,
                         int rows, int dff, int K, float p_drop, uint64_t seed, const int32_t* step_dev,
                         uint32_t stream_id, void* stream);
+
+/* ---- A projection and the row kernel behind it in ONE launch (csrc/gemm_rows.hip) ----------------------------------
+ * The product's 64-row x 512-column tiles stay on chip (LDS) and the workgroup that computed them runs the row
+ * kernel's arithmetic on them: the product's output never makes its HBM round trip.  bf16 operands, model width 512.
+ * mrmt3_gemm_rows_ok(M, N, K, lda, ldw): 1 when the fused kernels take the shape (N = 512, or 1024 for the GEGLU
+ * backward; K a multiple of 128; row strides multiples of 8 elements; buffers below 2 GiB) — otherwise call the two
+ * kernels.
+ *
+ * mrmt3_gemm_nt_addnorm = mrmt3_gemm_nt (y = A . W^T, [rows][512] bf16) + mrmt3_add_rmsnorm_fwd(x0, y, ...):
+ *   x1 = x0 + dropout(y) (f32, may be x0 itself or NULL), xn = w_norm * x1 * rsqrt(mean(x1^2) + eps) (bf16, dropped by
+ *   stream_out when out_drop != 0), rstd [rows] (nullable).  HF T5LayerSelfAttention / T5LayerCrossAttention / T5LayerFF:
+ *   `hidden + dropout(sublayer(...))` followed by the next sublayer's T5LayerNorm (models/t5.py:636-648).  Same bits as
+ *   the two kernels.
+ * mrmt3_gemm_nt_normbwd = mrmt3_gemm_nt (dxn = A . WT^T, [rows][512] bf16) + mrmt3_add_rmsnorm_bwd(dxn, dres, ...) with
+ *   out_drop = 0: dx1 (f32 or bf16, may be dres itself), dy_bf16 (masked by stream_y, nullable) and — when `workspace`
+ *   is given (mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, 512) bytes suffice) — the norm-weight gradient's partial rows,
+ *   mrmt3_gemm_nt_normbwd_partial_rows(rows) of them (one per 64 rows), left for mrmt3_norm_dw_reduce.
+ * mrmt3_gemm_nt_geglubwd = mrmt3_gemm_nt (dg = dy . WT^T, [rows][dff] bf16, WT = wo^T [dff][K]) + mrmt3_geglu_bwd(h, dg):
+ *   dh [rows][2 dff] bf16.  Same bits as the two kernels. */
+int mrmt3_gemm_rows_ok(int M, int N, int K, int lda, int ldw);
+/* diagnostics: while `buf` (device, [workgroups][8] uint64) is set, every fused launch leaves its workgroups' phase
+ * timestamps there (10-ns ticks: start, K loop start, K loop end, tile image written, end); NULL switches it off */
+int mrmt3_gemm_rows_trace(void* buf);
+int mrmt3_gemm_nt_addnorm(const void* A, int lda, const void* W, int ldw, int rows, int K, const float* x0,
+                          const float* w_norm, float eps, float* x1, void* xn_bf16, float* rstd, float p_drop,
+                          uint64_t seed, const int32_t* step_dev, uint32_t stream_y, uint32_t stream_out, int out_drop,
+                          void* stream);
+int mrmt3_gemm_nt_normbwd_partial_rows(int rows);
+int mrmt3_gemm_nt_normbwd(const void* A, int lda, const void* WT, int ldw, int rows, int K, const void* dres,
+                          int dres_dtype, const float* x1, const float* rstd, const float* w_norm, void* dx1,
+                          int dx1_dtype, void* dy_bf16, float p_drop, uint64_t seed, const int32_t* step_dev,
+                          uint32_t stream_y, void* workspace, size_t workspace_bytes, void* stream);
+int mrmt3_gemm_nt_geglubwd(const void* dy, int ldy, const void* WT, int ldw, const void* h, void* dh, int rows, int dff,
+                           int K, float p_drop, uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream);
 
 /* ---- K8: embedding gather + sinusoid add (+dropout) and its scatter-add backward ---------------
  * models/t5.py:539-540,596-601 and `_shift_right` (t5.py:148-150).

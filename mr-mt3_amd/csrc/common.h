@@ -127,4 +127,16 @@ __device__ __forceinline__ float gelu_new_f(float x) {
   return 0.5f * x * (1.0f + fast_tanh(c * (x + 0.044715f * (x * x * x))));
 }
 
+// gelu_new and its derivative (HF NewGELUActivation; the GEGLU backward, element-wise kernel and GEMM epilogue alike)
+__device__ __forceinline__ void gelu_new_fd(float x, float* f, float* d) {
+  const float c = 0.7978845608028654f;
+  const float t = fast_tanh(c * (x + 0.044715f * (x * x * x)));
+  *f = 0.5f * x * (1.0f + t);
+  *d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+// norm-weight gradient: per-workgroup partial rows are summed by DW_CHUNKS row chunks (rowops.hip: dw_reduce_body);
+// the workspace of a norm site is [partial rows | DW_CHUNKS chunk sums][cols] f32 + one arrival counter per 64 columns
+#define DW_CHUNKS 16
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

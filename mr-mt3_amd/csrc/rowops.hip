@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
 // groups) streams its rows with independent loads, the workgroup combines through LDS and leaves its 64 sums in
 // scratch[chunk]; the chunk workgroup that finishes last (agent-scope counter, zeroed by the norm-backward
 // kernel before) adds the DW_CHUNKS partials in chunk order: no float atomics, bitwise reproducible.
-#define DW_CHUNKS 16
 __device__ __forceinline__ void dw_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int n_part, int cols,
                                                float* __restrict__ scratch, int* __restrict__ counters) {
   // workgroup = 64 columns x one of DW_CHUNKS row chunks.  A thread = 4 columns (one 16-byte load per row) x 1 of 16
@@ -417,12 +416,7 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
 // gated GELU (HF T5DenseGatedGeluDense + NewGELUActivation)
 // ------------------------------------------------------------------------------------------------
 // (fast_tanh / gelu_new_f live in common.h: the GEGLU epilogue of gemm8.hip uses the same arithmetic)
-__device__ __forceinline__ void gelu_new_fd(float x, float* f, float* d) {
-  const float c = 0.7978845608028654f;
-  const float t = fast_tanh(c * (x + 0.044715f * (x * x * x)));
-  *f = 0.5f * x * (1.0f + t);
-  *d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
-}
+// (gelu_new_fd lives in common.h too: the GEGLU-backward epilogue of gemm_rows.hip uses the same arithmetic)
 
 // Both kernels move 8 elements (two dropout quads) per thread and iteration: 16-byte accesses for bf16.
 template <typename T>

@@ -85,6 +85,16 @@ class Engine:
         # ... and, for every shape the grouped kernel takes, the GEMMs themselves are deferred to the next join_wgrad():
         # one launch for the weight gradients of a whole gradient bucket (lib.TnGroup)
         self.tn_group = lib.TnGroup() if os.environ.get("MRMT3_TN_GROUP", "1") != "0" else None
+        # projection + row kernel in one launch (csrc/gemm_rows.hip; bf16 engine only).  MRMT3_FUSE_ROWS bits: 1 the o / co /
+        # wo projection with the residual add + norm behind it, 2 the 512-column data gradients with the norm backward,
+        # 4 the wo data gradient with the gated-GELU backward.  Same results as the two-kernel form (tests/test_gemm_rows_gpu.py).
+        # Default 6: same-box step A/B at 64 segments (profiles/r04_fuse_rows_step_ab.txt) 24.68 ms unfused, 24.25-24.29 with
+        # bit 4, 24.18 with bits 2 + 4 (K <= 1152), 24.45-24.47 when bit 1 is added — the forward fusion costs what it saves
+        # (its K loop is bound by the CU's L2 -> LDS rate and does not overlap its row phase)
+        self.fuse_rows = int(os.environ.get("MRMT3_FUSE_ROWS", "6")) if compute_dtype == torch.bfloat16 else 0
+        # the norm-backward fusion up to this K (d_cq 384, d_qkv 1152; d_wi, K = 2048, stays on the ping-pong product +
+        # the stand-alone row kernel: 224 against 205 us cold, profiles/r04_gemm_rows_ab.txt)
+        self.fuse_normbwd_max_k = int(os.environ.get("MRMT3_FUSE_NORMBWD_MAXK", "1152"))
 
     # ---- helpers ---------------------------------------------------------------------------------------
     def pos(self, device):
@@ -160,6 +170,35 @@ class Engine:
         return dx1, lib.dropmask_cast(dx1, p=p, seed=kw.get("seed", 0), stream_id=kw.get("stream_y", 0),
                                       step=kw.get("step"), out_dtype=torch.float32)
 
+    def _proj_addnorm(self, x, pend, w_norm, xn_dtype=None, **kw):
+        """add_rmsnorm_fwd(x, y, ...) where y is the pending projection `pend` = (a, W) of the sublayer above (None: the
+        stack's first norm, nothing to add): one fused launch when the shape allows, else the product then the row kernel."""
+        xn_dtype = xn_dtype or self.dt
+        if pend is None:
+            return lib.add_rmsnorm_fwd(x, None, w_norm, self.eps, xn_dtype, **kw)
+        a, w = pend
+        if ((self.fuse_rows & 1) and self.y_dtype == torch.bfloat16 and xn_dtype == torch.bfloat16 and x.shape[1] == 512 and
+                lib.gemm_rows_ok(a, w)):
+            return lib.gemm_nt_addnorm(a, w, x, w_norm, self.eps, **kw)
+        y = lib.gemm_nt(a, w, out_dtype=self.y_dtype)
+        return lib.add_rmsnorm_fwd(x, y, w_norm, self.eps, xn_dtype, **kw)
+
+    def _proj_norm_bwd(self, a, wt, dres, x1, rstd, w_norm, dw, **kw):
+        """_norm_bwd(gemm_nt(a, wt), dres, ...): the data gradient of a sublayer's input projection and the backward of the
+        norm in front of it, one fused launch when the shape allows."""
+        if ((self.fuse_rows & 2) and self.y_dtype == torch.bfloat16 and dres is not None and x1.shape[1] == 512 and
+                a.shape[1] <= self.fuse_normbwd_max_k and lib.gemm_rows_ok(a, wt)):
+            return lib.gemm_nt_normbwd(a, wt, dres, x1, rstd, w_norm, dw, defer=self.norm_dw, **kw)
+        dxn = lib.gemm_nt(a, wt, out_dtype=self.y_dtype)
+        return self._norm_bwd(dxn, dres, x1, rstd, w_norm, dw, **kw)
+
+    def _proj_geglu_bwd(self, dy, wt, h, **kw):
+        """geglu_bwd(h, gemm_nt(dy, wt)): the wo data gradient and the gated-GELU backward."""
+        if (self.fuse_rows & 4) and h.dtype == torch.bfloat16 and lib.gemm_rows_ok(dy, wt, N=wt.shape[0]):
+            return lib.gemm_nt_geglubwd(dy, wt, h, **kw)
+        dg = lib.gemm_nt(dy, wt)
+        return lib.geglu_bwd(h, dg, **kw)
+
     def flush_norm_dw(self):
         if self.norm_dw is not None:
             self.norm_dw.flush()
@@ -211,7 +250,7 @@ class Engine:
         (and dropped) states [B*L, d] in the compute dtype."""
         f, dt, H, inner, eps = self.flat, self.dt, self.H, self.inner, self.eps
         keep = tape is not None
-        y = None
+        pend = None          # the projection of the sublayer above, not yet added to the residual stream: (operand, weight)
         sy = 0
         # cross-attention K | V of every layer in one projection of the encoder output: [B*Le, n_layers * 768]
         kv_all = lib.gemm_nt(enc, self.W(f"{prefix}.ckv_all")) if is_decoder and n_layers > 0 else None
@@ -219,14 +258,14 @@ class Engine:
             b = f"{prefix}.block.{i}.layer"
             # -- self attention
             s_in = sy
-            x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.0.layer_norm.weight"), eps, dt, write_x1=True,
-                                              p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
+            x, xn, rstd = self._proj_addnorm(x, pend, self.ln(f"{b}.0.layer_norm.weight"), write_x1=True,
+                                             p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
             qkv = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.qkv"))
             s_att = self._sid()
             o, lse, o_lo = lib.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, H, L, L,
                                         is_decoder, p=p, seed=self.seed, step=self.step_dev, stream_id=s_att,
                                         want_lse=keep, want_lo=keep and self.lo_sites == "all")
-            y = lib.gemm_nt(o, self.W(f"{prefix}.{i}.o"), out_dtype=self.y_dtype)
+            pend = (o, self.W(f"{prefix}.{i}.o"))
             sy = self._sid()
             if keep:
                 tape.push(kind="self", i=i, x1=x, xn=xn, rstd=rstd, qkv=qkv, o=o, o_lo=o_lo, lse=lse, s_in=s_in,
@@ -234,14 +273,14 @@ class Engine:
             ff = 1
             if is_decoder and enc is not None:
                 s_in = sy
-                x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.1.layer_norm.weight"), eps, dt,
-                                                  p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
+                x, xn, rstd = self._proj_addnorm(x, pend, self.ln(f"{b}.1.layer_norm.weight"),
+                                                 p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
                 q = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.cq"))
                 kv = kv_all[:, i * 2 * inner:(i + 1) * 2 * inner]        # this layer's K | V columns (row stride n_layers * 768)
                 s_att = self._sid()
                 o, lse, o_lo = lib.attn_fwd(q, kv[:, :inner], kv[:, inner:], B, H, L, Le, False, p=p, seed=self.seed,
                                             step=self.step_dev, stream_id=s_att, want_lse=keep, want_lo=keep)
-                y = lib.gemm_nt(o, self.W(f"{prefix}.{i}.co"), out_dtype=self.y_dtype)
+                pend = (o, self.W(f"{prefix}.{i}.co"))
                 sy = self._sid()
                 if keep:
                     tape.push(kind="cross", i=i, x1=x, xn=xn, rstd=rstd, q=q, kv=kv, o=o, o_lo=o_lo, lse=lse,
@@ -249,22 +288,22 @@ class Engine:
                 ff = 2
             # -- gated-GELU feed forward
             s_in = sy
-            x, xn, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{b}.{ff}.layer_norm.weight"), eps, dt,
-                                              p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
+            x, xn, rstd = self._proj_addnorm(x, pend, self.ln(f"{b}.{ff}.layer_norm.weight"),
+                                             p=p, seed=self.seed, step=self.step_dev, stream_y=s_in, x1=None if keep else x)
             s_g = self._sid()
             if xn.dtype == torch.bfloat16:         # K2 + K7 in one launch (same bits as the two kernels)
                 h, g = lib.gemm_nt_geglu(xn, self.W(f"{prefix}.{i}.wi"), p=p, seed=self.seed, step=self.step_dev, stream_id=s_g)
             else:
                 h = lib.gemm_nt(xn, self.W(f"{prefix}.{i}.wi"))
                 g = lib.geglu_fwd(h, p=p, seed=self.seed, step=self.step_dev, stream_id=s_g)
-            y = lib.gemm_nt(g, self.W(f"{prefix}.{i}.wo"), out_dtype=self.y_dtype)
+            pend = (g, self.W(f"{prefix}.{i}.wo"))
             sy = self._sid()
             if keep:
                 tape.push(kind="ff", i=i, ff=ff, x1=x, xn=xn, rstd=rstd, h=h, g=g, s_in=s_in, s_g=s_g)
         s_out = self._sid()
-        x, out, rstd = lib.add_rmsnorm_fwd(x, y, self.ln(f"{prefix}.final_layer_norm.weight"), eps, out_dtype or dt, p=p,
-                                           seed=self.seed, step=self.step_dev, stream_y=sy, stream_out=s_out, out_drop=True,
-                                           x1=None if keep else x)
+        x, out, rstd = self._proj_addnorm(x, pend, self.ln(f"{prefix}.final_layer_norm.weight"), xn_dtype=out_dtype or dt, p=p,
+                                          seed=self.seed, step=self.step_dev, stream_y=sy, stream_out=s_out, out_drop=True,
+                                          x1=None if keep else x)
         if keep:
             tape.push(kind="final", x1=x, rstd=rstd, s_in=sy, s_out=s_out, prefix=prefix, n_layers=n_layers,
                       is_decoder=is_decoder, B=B, L=L, Le=Le, enc=enc, p=p)
@@ -295,13 +334,12 @@ class Engine:
             assert t["kind"] == "ff" and t["i"] == i
             ff = t["ff"]
             self.wgrad(dy, t["g"], f.GW(f"{prefix}.{i}.wo"))
-            dg = lib.gemm_nt(dy, self.WT(f"{prefix}.{i}.wo"))
-            dh = lib.geglu_bwd(t["h"], dg, p=p, seed=seed, step=self.step_dev, stream_id=t["s_g"])
+            dh = self._proj_geglu_bwd(dy, self.WT(f"{prefix}.{i}.wo"), t["h"], p=p, seed=seed, step=self.step_dev,
+                                      stream_id=t["s_g"])
             self.wgrad(dh, t["xn"], f.GW(f"{prefix}.{i}.wi"))
-            dxn = lib.gemm_nt(dh, self.WT(f"{prefix}.{i}.wi"), out_dtype=self.y_dtype)
-            dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.{ff}.layer_norm.weight"),
-                                         f.grad(f"{b}.{ff}.layer_norm.weight"), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
-                                         dx1=dx)
+            dx, dy = self._proj_norm_bwd(dh, self.WT(f"{prefix}.{i}.wi"), dx, t["x1"], t["rstd"],
+                                         self.ln(f"{b}.{ff}.layer_norm.weight"), f.grad(f"{b}.{ff}.layer_norm.weight"),
+                                         p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"], dx1=dx)
             if ff == 2:
                 t = tape.pop()
                 assert t["kind"] == "cross"
@@ -315,10 +353,9 @@ class Engine:
                              stream_id=t["s_att"], o_lo=t["o_lo"])
                 self.wgrad(dq, t["xn"], f.GW(f"{prefix}.{i}.cq"))
                 self.wgrad(dkv, enc, f.GW(f"{prefix}.{i}.ckv"))
-                dxn = lib.gemm_nt(dq, self.WT(f"{prefix}.{i}.cq"), out_dtype=self.y_dtype)
-                dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.1.layer_norm.weight"),
-                                             f.grad(f"{b}.1.layer_norm.weight"), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
-                                             dx1=dx)
+                dx, dy = self._proj_norm_bwd(dq, self.WT(f"{prefix}.{i}.cq"), dx, t["x1"], t["rstd"],
+                                             self.ln(f"{b}.1.layer_norm.weight"), f.grad(f"{b}.1.layer_norm.weight"),
+                                             p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"], dx1=dx)
             t = tape.pop()
             assert t["kind"] == "self" and t["i"] == i
             self.wgrad(dy, t["o"], f.GW(f"{prefix}.{i}.o"))
@@ -329,11 +366,11 @@ class Engine:
                          dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, H, L, L, is_dec, p=p,
                          seed=seed, step=self.step_dev, stream_id=t["s_att"], o_lo=t["o_lo"])
             self.wgrad(dqkv, t["xn"], f.GW(f"{prefix}.{i}.qkv"))
-            dxn = lib.gemm_nt(dqkv, self.WT(f"{prefix}.{i}.qkv"), out_dtype=self.y_dtype)
             last = i == 0                                     # the stack's input gradient leaves in f32
-            dx, dy = self._norm_bwd(dxn, dx, t["x1"], t["rstd"], self.ln(f"{b}.0.layer_norm.weight"),
-                                         f.grad(f"{b}.0.layer_norm.weight"), want_dy=(i > 0), p=p, seed=seed, step=self.step_dev,
-                                         stream_y=t["s_in"], dx1=None if (last and dx.dtype != torch.float32) else dx)
+            dx, dy = self._proj_norm_bwd(dqkv, self.WT(f"{prefix}.{i}.qkv"), dx, t["x1"], t["rstd"],
+                                         self.ln(f"{b}.0.layer_norm.weight"), f.grad(f"{b}.0.layer_norm.weight"),
+                                         want_dy=(i > 0), p=p, seed=seed, step=self.step_dev, stream_y=t["s_in"],
+                                         dx1=None if (last and dx.dtype != torch.float32) else dx)
             if on_layer_done is not None:
                 on_layer_done(prefix, i)
         if dkv_all is not None:

@@ -45,6 +45,12 @@ _SIGS = {
                             ci, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_gemm_nt_geglu": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
+    "mrmt3_gemm_rows_ok": (ci, [ci, ci, ci, ci, ci]),
+    "mrmt3_gemm_rows_trace": (ci, [vp]),
+    "mrmt3_gemm_nt_addnorm": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, cf, vp, vp, vp, cf, cu64, vp, cu32, cu32, ci, vp]),
+    "mrmt3_gemm_nt_normbwd_partial_rows": (ci, [ci]),
+    "mrmt3_gemm_nt_normbwd": (ci, [vp, ci, vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, ci, vp, cf, cu64, vp, cu32, vp, csz, vp]),
+    "mrmt3_gemm_nt_geglubwd": (ci, [vp, ci, vp, ci, vp, vp, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_tn_group_ok": (ci, [ci, ci, ci, ci, ci, ci]),
     "mrmt3_tn_group_plan": (ci, [vp, ci, vp, vp, C.c_size_t, vp]),
     "mrmt3_tn_group_run": (ci, [vp, vp, vp, vp]),
@@ -120,9 +126,10 @@ def load():
     return lib
 
 
-MIN_VERSION = 104
+MIN_VERSION = 105
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
-                 "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk")
+                 "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
+                 "gemm_nt_geglubwd")
 
 
 def dispatch_counts(reset: bool = False) -> dict:
@@ -526,8 +533,11 @@ class NormDwBatch:
         self._queue = []       # [(key, dw tensor)]
         self._tables = {}      # tuple(keys) -> (ws addresses, dw addresses, partial rows) device tensors
 
-    def site(self, dw, rows, cols):
-        key = (dw.data_ptr(), rows, cols)
+    def site(self, dw, rows, cols, n_part=None):
+        """`n_part`: partial rows the producing kernel leaves (default: the stand-alone norm backward's count)."""
+        if n_part is None:
+            n_part = load().mrmt3_add_rmsnorm_bwd_partial_rows(rows)
+        key = (dw.data_ptr(), rows, cols, n_part)
         ws = self._ws.get(key)
         if ws is None:
             ws = torch.empty(load().mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, cols), device=dw.device, dtype=torch.uint8)
@@ -543,10 +553,9 @@ class NormDwBatch:
             tab = self._tables.get(keys)
             dev = self._queue[0][1].device
             if tab is None:
-                L = load()
                 tab = (torch.tensor([self._ws[k].data_ptr() for k in keys], dtype=torch.int64, device=dev),
                        torch.tensor([k[0] for k in keys], dtype=torch.int64, device=dev),
-                       torch.tensor([L.mrmt3_add_rmsnorm_bwd_partial_rows(k[1]) for k in keys], dtype=torch.int32, device=dev))
+                       torch.tensor([k[3] for k in keys], dtype=torch.int32, device=dev))
                 self._tables[keys] = tab
             _check(load().mrmt3_norm_dw_reduce(_p(tab[0]), _p(tab[1]), _p(tab[2]), len(keys), cols, _stream()),
                    "norm_dw_reduce")
@@ -683,6 +692,87 @@ def gemm_nt_geglu(x, wi, p=0.0, seed=0, stream_id=0, step=None):
         _check(load().mrmt3_gemm_nt_geglu(_p(x), x.stride(0), _p(wi), wi.stride(0), _p(h), two, _p(g), two // 2, rows,
                                           two // 2, K, p, seed, _p(step), stream_id, _stream()), "gemm_nt_geglu")
     return h, g
+
+
+def gemm_rows_ok(a, w, N=512):
+    """True when the fused projection + row kernels (gemm_rows.hip) take a [M, K] x [N, K]^T product of these operands."""
+    return (a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2 and
+            a.stride(1) == 1 and w.stride(1) == 1 and w.shape[0] == N and a.shape[1] == w.shape[1] and
+            bool(load().mrmt3_gemm_rows_ok(a.shape[0], N, a.shape[1], a.stride(0), w.stride(0))))
+
+
+def _rows_bytes(M, N, K, row_bytes):
+    """algorithmic bytes of a fused launch: operands once + `row_bytes` per output element of the row operands"""
+    return (M * K + N * K) * 2 + M * N * row_bytes
+
+
+def gemm_nt_addnorm(a, w_proj, x0, w_norm, eps, write_x1=True, p=0.0, seed=0, stream_y=0, stream_out=0, out_drop=False,
+                    x1=None, step=None):
+    """(x1, xn, rstd) = add_rmsnorm_fwd(x0, gemm_nt(a, w_proj), w_norm, ...) in ONE launch (bf16; same bits)."""
+    _dev(a, w_proj, x0, w_norm)
+    rows, K = a.shape
+    assert x0.shape == (rows, 512) and x0.dtype == torch.float32 and x0.is_contiguous()
+    if x1 is None and write_x1:
+        x1 = torch.empty_like(x0)
+    xn = torch.empty(rows, 512, device=a.device, dtype=torch.bfloat16)
+    rstd = torch.empty(rows, device=a.device, dtype=torch.float32)
+    if PROFILE is not None:
+        PROFILE_BYTES["gemm_nt_addnorm_bf16"] = PROFILE_BYTES.get("gemm_nt_addnorm_bf16", 0.0) + _rows_bytes(rows, 512, K, 10)
+    with _Timed("gemm_nt_addnorm_bf16", 2.0 * rows * 512 * K, "FLOP"):
+        _check(load().mrmt3_gemm_nt_addnorm(_p(a), a.stride(0), _p(w_proj), w_proj.stride(0), rows, K, _p(x0), _p(w_norm),
+                                            eps, _p(x1), _p(xn), _p(rstd), p, seed, _p(step), stream_y, stream_out,
+                                            int(out_drop), _stream()), "gemm_nt_addnorm")
+    return (x1 if x1 is not None else x0), xn, rstd
+
+
+def gemm_nt_normbwd(a, wt, dres, x1, rstd, w_norm, dw, want_dy=True, p=0.0, seed=0, stream_y=0, dx1=None,
+                    dx1_dtype=torch.float32, defer=None, step=None):
+    """(dx1, dy) = add_rmsnorm_bwd(gemm_nt(a, wt), dres, x1, rstd, w_norm, dw, ...) in ONE launch (bf16 product)."""
+    _dev(a, wt, dres, x1, rstd, w_norm)
+    rows, K = a.shape
+    assert x1.shape == (rows, 512) and dres is not None and dres.shape == (rows, 512)
+    if dx1 is None:
+        dx1 = torch.empty(rows, 512, device=a.device, dtype=dx1_dtype)
+    dy = torch.empty(rows, 512, device=a.device, dtype=torch.bfloat16) if want_dy else None
+    L = load()
+    n_part = L.mrmt3_gemm_nt_normbwd_partial_rows(rows)
+    reduce_now = None
+    if dw is None:
+        ws = None
+    elif defer is not None:
+        ws = defer.site(dw, rows, 512, n_part)
+    else:
+        ws = workspace(L.mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, 512), a.device)
+        reduce_now = dw
+    if PROFILE is not None:
+        PROFILE_BYTES["gemm_nt_normbwd_bf16"] = PROFILE_BYTES.get("gemm_nt_normbwd_bf16", 0.0) + _rows_bytes(
+            rows, 512, K, 4 + dres.element_size() + dx1.element_size() + (2 if want_dy else 0))
+    with _Timed("gemm_nt_normbwd_bf16", 2.0 * rows * 512 * K, "FLOP"):
+        _check(L.mrmt3_gemm_nt_normbwd(_p(a), a.stride(0), _p(wt), wt.stride(0), rows, K, _p(dres), _dt(dres), _p(x1),
+                                       _p(rstd), _p(w_norm), _p(dx1), _dt(dx1), _p(dy), p, seed, _p(step), stream_y,
+                                       _p(ws), ws.numel() if ws is not None else 0, _stream()), "gemm_nt_normbwd")
+    if reduce_now is not None:
+        dev = a.device
+        tab = (torch.tensor([ws.data_ptr()], dtype=torch.int64, device=dev),
+               torch.tensor([dw.data_ptr()], dtype=torch.int64, device=dev),
+               torch.tensor([n_part], dtype=torch.int32, device=dev))
+        _check(L.mrmt3_norm_dw_reduce(_p(tab[0]), _p(tab[1]), _p(tab[2]), 1, 512, _stream()), "norm_dw_reduce")
+    return dx1, dy
+
+
+def gemm_nt_geglubwd(dy, wt, h, p=0.0, seed=0, stream_id=0, step=None):
+    """dh = geglu_bwd(h, gemm_nt(dy, wt)) in ONE launch (wt = wo^T [dff, d]; bf16; same bits)."""
+    _dev(dy, wt, h)
+    rows, K = dy.shape
+    dff = wt.shape[0]
+    assert h.shape == (rows, 2 * dff) and h.dtype == torch.bfloat16 and h.is_contiguous()
+    dh = torch.empty_like(h)
+    if PROFILE is not None:
+        PROFILE_BYTES["gemm_nt_geglubwd_bf16"] = PROFILE_BYTES.get("gemm_nt_geglubwd_bf16", 0.0) + _rows_bytes(rows, dff, K, 8)
+    with _Timed("gemm_nt_geglubwd_bf16", 2.0 * rows * dff * K, "FLOP"):
+        _check(load().mrmt3_gemm_nt_geglubwd(_p(dy), dy.stride(0), _p(wt), wt.stride(0), _p(h), _p(dh), rows, dff, K, p,
+                                             seed, _p(step), stream_id, _stream()), "gemm_nt_geglubwd")
+    return dh
 
 
 def geglu_bwd(h, dg, p=0.0, seed=0, stream_id=0, step=None):
