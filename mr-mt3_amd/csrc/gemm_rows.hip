@@ -128,10 +128,10 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
   const int m0 = mt * BM, n0 = nt * 512;
 #define GR_STAMP(i) do { if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GR_STAMP(0);
-  // (experiment, MRMT3_ROWS_SKEW_FINE: four start phases so that not every CU is in its K loop — HBM idle — and then in
+  // (experiment, MRMT3_ROWS_SKEW_FINE: two start phases so that not every CU is in its K loop — HBM idle — and then in
   // its row phase at the same time)
   if (P.skew_fine > 0) {
-    const unsigned long long wait = (unsigned long long)(((int)blockIdx.x >> 3) & 3) * P.skew_fine;
+    const unsigned long long wait = (unsigned long long)(((int)blockIdx.x >> 3) & 1) * P.skew_fine;
     if (wait) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
@@ -157,18 +157,26 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
   unsigned char* const ldsA = lds + GR_B_BYTES + w * 1024;
   unsigned char* const ldsB = lds + w * 8192;
   const int np = (P.dbg & 1) ? 0 : P.K >> 6;
+  // (experiment, MRMT3_ROWS_DBG bit 256: every workgroup walks the K chunks from a different starting chunk, so that the
+  // CUs of an XCD do not all ask the L2 for the same weight lines at the same time)
+  const int rot = (P.dbg & 256) && np > 0 ? (int)((blockIdx.x >> 3) % (unsigned)np) : 0;   // (blocks b, b + 8, ... share an XCD)
+  auto koff = [&](int chunk) __attribute__((always_inline)) -> int {
+    int c = chunk + rot;
+    if (c >= np) c -= np;
+    return c * 128;
+  };
 
   auto ldA = [&](int slot, int chunk) __attribute__((always_inline)) {
     const bool on = chunk < np && !(P.dbg & 32);
 #pragma unroll
-    for (int q = 0; q < NAP; ++q) gr_dma16(ra, ldsA + slot * A_SLOT + q * 8192, voffA, on ? chunk * 128 + q * astride : GR_OOB);
+    for (int q = 0; q < NAP; ++q) gr_dma16(ra, ldsA + slot * A_SLOT + q * 8192, voffA, on ? koff(chunk) + q * astride : GR_OOB);
   };
   // B of K chunk `chunk` (64 deep), column half ch -> this wave's slot ch
   auto ldB = [&](int ch, int chunk) __attribute__((always_inline)) {
     const bool on = chunk < np && !(P.dbg & 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      gr_dma16(rb, ldsB + ch * 4096 + q * 1024, voffB, on ? chunk * 128 + (ch * 4 + q) * qstride : GR_OOB);
+      gr_dma16(rb, ldsB + ch * 4096 + q * 1024, voffB, on ? koff(chunk) + (ch * 4 + q) * qstride : GR_OOB);
   };
 
   // fragment read offsets (128-byte rows, chunk c of row r at c ^ (r & 7); the second 32-deep K step is the offset ^ 64)
@@ -255,67 +263,81 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
   if (P.dbg & 2) return;
   // ---- rows: wave w takes tile rows w, w + 8, ...
   if constexpr (EPI == GR_ADDNORM) {
+    // The stand-alone row kernel hides its per-row dependency chains (LDS read -> mask -> sum of squares -> six shuffle
+    // steps -> rsqrt -> stores) behind 32 waves per CU; here 8 or 16 waves run the rows, so the chains of ALL of a wave's
+    // rows are walked side by side: one pass per stage over the rows (same arithmetic per row, same bits), every global
+    // load of the wave's rows requested before the first is used.
     const DropCfg dy = dc0, dout = dc1;
     float wv[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) gr_load4<false>(P.wn, i * 256 + lane * 4, wv[i]);
+    constexpr int G = RPW;                       // rows per group: all of the wave's rows (8 or 16)
+    f32x4 xv[G][2];
 #pragma unroll
-    for (int grp = 0; grp < RPW / 8; ++grp) {
-      f32x4 xv[8][2];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int row = m0 + w + 8 * (grp * 8 + t);
-        if (row < P.M) {
-          const float* px = P.xin + (size_t)row * 512 + lane * 4;
-          if (P.cache_mode & 2) { xv[t][0] = __builtin_nontemporal_load((const f32x4*)px); xv[t][1] = __builtin_nontemporal_load((const f32x4*)(px + 256)); }
-          else { xv[t][0] = *(const f32x4*)px; xv[t][1] = *(const f32x4*)(px + 256); }
-        }
+    for (int t = 0; t < G; ++t) {
+      const int row = m0 + w + 8 * t;
+      if (row < P.M) {
+        const float* px = P.xin + (size_t)row * 512 + lane * 4;
+        if (P.cache_mode & 2) { xv[t][0] = __builtin_nontemporal_load((const f32x4*)px); xv[t][1] = __builtin_nontemporal_load((const f32x4*)(px + 256)); }
+        else { xv[t][0] = *(const f32x4*)px; xv[t][1] = *(const f32x4*)(px + 256); }
       }
+    }
+    float ss[G];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int lr = w + 8 * (grp * 8 + t), row = m0 + lr;
-        if (row >= P.M) continue;
-        const size_t base = (size_t)row * 512;
-        float v[2][4];
-        float ss = 0.f;
+    for (int t = 0; t < G; ++t) {
+      const int lr = w + 8 * t, row = m0 + lr;
+      ss[t] = 0.f;
+      if (row >= P.M) continue;
+      const size_t base = (size_t)row * 512;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int col = i * 256 + lane * 4;
-          v[i][0] = xv[t][i].x; v[i][1] = xv[t][i].y; v[i][2] = xv[t][i].z; v[i][3] = xv[t][i].w;
-          float yv[4];
-          gr_unpack4(*(const u32x2*)(lds + lr * GR_YLD + col * 2), yv);
-          if (dy.thresh) {
-            float m[4];
-            drop_mask4(dy, (base + col) >> 2, m);
+      for (int i = 0; i < 2; ++i) {
+        const int col = i * 256 + lane * 4;
+        float v[4] = {xv[t][i].x, xv[t][i].y, xv[t][i].z, xv[t][i].w};
+        float yv[4];
+        gr_unpack4(*(const u32x2*)(lds + lr * GR_YLD + col * 2), yv);
+        if (dy.thresh) {
+          float m[4];
+          drop_mask4(dy, (base + col) >> 2, m);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) yv[e] *= m[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[i][e] += yv[e];
-          if (P.x1 != nullptr) {
-            if (P.cache_mode & 1) __builtin_nontemporal_store((f32x4{v[i][0], v[i][1], v[i][2], v[i][3]}), (f32x4*)(P.x1 + base + col));
-            else *(f32x4*)(P.x1 + base + col) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
+          for (int e = 0; e < 4; ++e) yv[e] *= m[e];
         }
-        ss = wave_sum(ss);
-        const float rstd = rsqrtf(ss / 512.0f + P.eps);
-        if (lane == 0 && P.rstd != nullptr) P.rstd[row] = rstd;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int col = i * 256 + lane * 4;
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = wv[i][e] * (v[i][e] * rstd);
-          if (P.out_drop && dout.thresh) {
-            float m[4];
-            drop_mask4(dout, (base + col) >> 2, m);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] *= m[e];
-          }
-          gr_store4<true>(P.xn, base + col, o);
+        for (int e = 0; e < 4; ++e) v[e] += yv[e];
+        xv[t][i] = f32x4{v[0], v[1], v[2], v[3]};
+        if (P.x1 != nullptr) {
+          if (P.cache_mode & 1) __builtin_nontemporal_store(xv[t][i], (f32x4*)(P.x1 + base + col));
+          else *(f32x4*)(P.x1 + base + col) = xv[t][i];
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss[t] += v[e] * v[e];
+      }
+    }
+    // wave_sum of every row, the rows' butterflies interleaved (per row: the same six steps in the same order)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int t = 0; t < G; ++t) ss[t] += __shfl_xor(ss[t], o, 64);
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+      const int row = m0 + w + 8 * t;
+      if (row >= P.M) continue;
+      const size_t base = (size_t)row * 512;
+      const float rstd = rsqrtf(ss[t] / 512.0f + P.eps);
+      if (lane == 0 && P.rstd != nullptr) P.rstd[row] = rstd;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int col = i * 256 + lane * 4;
+        const float v[4] = {xv[t][i].x, xv[t][i].y, xv[t][i].z, xv[t][i].w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = wv[i][e] * (v[e] * rstd);
+        if (P.out_drop && dout.thresh) {
+          float m[4];
+          drop_mask4(dout, (base + col) >> 2, m);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= m[e];
+        }
+        gr_store4<true>(P.xn, base + col, o);
       }
     }
   } else if constexpr (EPI == GR_NORMBWD) {
@@ -327,16 +349,18 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
 #pragma unroll
       for (int e = 0; e < 4; ++e) dwp[i][e] = 0.f;
     }
-    // groups of 4 rows: x1 (f32) + the residual gradient of more rows would not fit beside the rest in 128 VGPRs (BM 64)
+    // groups of G rows, their dependency chains side by side (see the forward).  G = 4 with 128 VGPRs (64-row tiles): x1
+    // (f32) + the residual gradient of more rows would not fit; 8 with 256
+    constexpr int G = BM == 128 ? (RI ? 8 : 4) : 2;
 #pragma unroll
-    for (int grp = 0; grp < RPW / 4; ++grp) {
+    for (int grp = 0; grp < RPW / G; ++grp) {
       typedef typename std::conditional<RI, u32x2, f32x4>::type RawR;
-      f32x4 xv[4][2];
-      RawR rr[4][2];
-      float rs[4];
+      f32x4 xv[G][2];
+      RawR rr[G][2];
+      float rs[G];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = m0 + w + 8 * (grp * 4 + t);
+      for (int t = 0; t < G; ++t) {
+        const int row = m0 + w + 8 * (grp * G + t);
         if (row < P.M) {
           const size_t base = (size_t)row * 512;
           xv[t][0] = *(const f32x4*)(P.xin + base + lane * 4);
@@ -346,34 +370,45 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
           rs[t] = P.rstd[row];
         }
       }
+      float g[G][2][4], dot[G];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int lr = w + 8 * (grp * 4 + t), row = m0 + lr;
+      for (int t = 0; t < G; ++t) {
+        const int lr = w + 8 * (grp * G + t), row = m0 + lr;
+        dot[t] = 0.f;
         if (row >= P.M) continue;
-        const size_t base = (size_t)row * 512;
         const float rstd = rs[t];
-        float g[2][4], xh[2][4];
-        float dot = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int col = i * 256 + lane * 4;
-          gr_unpack4(*(const u32x2*)(lds + lr * GR_YLD + col * 2), g[i]);
-          xh[i][0] = xv[t][i].x; xh[i][1] = xv[t][i].y; xh[i][2] = xv[t][i].z; xh[i][3] = xv[t][i].w;
+          gr_unpack4(*(const u32x2*)(lds + lr * GR_YLD + col * 2), g[t][i]);
+          float xh[4] = {xv[t][i].x, xv[t][i].y, xv[t][i].z, xv[t][i].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            xh[i][e] *= rstd;
-            dwp[i][e] += g[i][e] * xh[i][e];
-            g[i][e] *= wv[i][e];
-            dot += g[i][e] * xh[i][e];
+            xh[e] *= rstd;
+            dwp[i][e] += g[t][i][e] * xh[e];
+            g[t][i][e] *= wv[i][e];
+            dot[t] += g[t][i][e] * xh[e];
           }
+          xv[t][i] = f32x4{xh[0], xh[1], xh[2], xh[3]};
         }
-        dot = wave_sum(dot) / 512.0f;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int t = 0; t < G; ++t) dot[t] += __shfl_xor(dot[t], o, 64);
+#pragma unroll
+      for (int t = 0; t < G; ++t) {
+        const int row = m0 + w + 8 * (grp * G + t);
+        if (row >= P.M) continue;
+        const size_t base = (size_t)row * 512;
+        const float rstd = rs[t], dt = dot[t] / 512.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int col = i * 256 + lane * 4;
+          const float xh[4] = {xv[t][i].x, xv[t][i].y, xv[t][i].z, xv[t][i].w};
           float d[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) d[e] = rstd * (g[i][e] - xh[i][e] * dot);
+          for (int e = 0; e < 4; ++e) d[e] = rstd * (g[t][i][e] - xh[e] * dt);
           float rv[4];
           if constexpr (RI) gr_unpack4(rr[t][i], rv);
           else { rv[0] = rr[t][i].x; rv[1] = rr[t][i].y; rv[2] = rr[t][i].z; rv[3] = rr[t][i].w; }
@@ -408,12 +443,13 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
   } else {
     const DropCfg d = dc0;
     const int dff = P.dff;
+    constexpr int G = BM == 128 ? 8 : 4;
 #pragma unroll
-    for (int grp = 0; grp < RPW / 4; ++grp) {
-      u32x4 hv[4][2];
+    for (int grp = 0; grp < RPW / G; ++grp) {
+      u32x4 hv[G][2];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = m0 + w + 8 * (grp * 4 + t);
+      for (int t = 0; t < G; ++t) {
+        const int row = m0 + w + 8 * (grp * G + t);
         if (row < P.M) {
           const bf16_t* ph = P.h + (size_t)row * 2 * dff + n0 + lane * 8;
           if (P.cache_mode & 1) { hv[t][0] = __builtin_nontemporal_load((const u32x4*)ph); hv[t][1] = __builtin_nontemporal_load((const u32x4*)(ph + dff)); }
@@ -421,8 +457,8 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int lr = w + 8 * (grp * 4 + t), row = m0 + lr;
+      for (int t = 0; t < G; ++t) {
+        const int lr = w + 8 * (grp * G + t), row = m0 + lr;
         if (row >= P.M) continue;
         const u32x4 gv = *(const u32x4*)(lds + lr * GR_YLD + lane * 16);
         float a[8], b[8], go[8], da[8], db[8];
