@@ -2,7 +2,11 @@
 workgroup) is bitwise repeatable alone and beside a second log-mel loop, but not beside a training process
 (profiles/r03_two_process_soak.txt).  Here a victim process loops log-mel and compares every result with its first,
 while an aggressor process loops ONE kernel family at benchmark shapes; one victim / aggressor pair per family.
-    python3 profiles/tools/lds_victim.py [seconds per family = 20]"""
+    python3 profiles/tools/lds_victim.py [seconds per family = 20]
+    python3 profiles/tools/lds_victim.py --inprocess [seconds per family = 20] [families]
+--inprocess (round 4): ONE process, the log-mel loop on stream A and the aggressor family on stream B
+at the same time — the product's own configuration whenever the eager two-stream path or RCCL kernels run beside
+compute.  Every victim launch is compared with the first result on the device."""
 import os
 import subprocess
 import sys
@@ -13,7 +17,7 @@ FAMILIES = ["gemm_nt8", "gemm_nt_tile", "gemm_nt_geglu", "tn_group", "gemm_tn_ti
             "rowops", "ce_adamw", "torch_matmul"]
 
 
-def aggressor(family, seconds):
+def aggressor(family, seconds, build_only=False):
     sys.path.insert(0, os.path.join(ROOT, "mr-mt3_amd"))
     import torch
     from mrmt3 import lib
@@ -75,6 +79,8 @@ def aggressor(family, seconds):
     else:
         a = torch.randn(4096, 4096, device=dev).bfloat16()
         fn = lambda: a @ a
+    if build_only:
+        return fn
     t0 = time.time()
     n = 0
     while time.time() - t0 < seconds:
@@ -83,6 +89,39 @@ def aggressor(family, seconds):
         torch.cuda.synchronize()
         n += 20
     print("aggressor %s: %d launches in %.0f s" % (family, n, time.time() - t0), flush=True)
+
+
+def inprocess(family, seconds):
+    """victim and aggressor in ONE process on two streams; returns (victim launches, launches with a wrong frame,
+    aggressor launches, fraction of the victim's time an aggressor kernel was queued beside it)."""
+    sys.path.insert(0, os.path.join(ROOT, "mr-mt3_amd"))
+    import torch
+    from contrib import spectrograms as sp
+    from mrmt3.synthetic import synth_audio
+    dev = torch.device("cuda:0")
+    fn = aggressor(family, 0, build_only=True)
+    audio = torch.from_numpy(synth_audio(2, seed=51)).to(dev)
+    ref = sp.logmel_segments(audio, out_bf16=True).clone()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    nbad = torch.zeros((), device=dev, dtype=torch.int64)
+    torch.cuda.synchronize()
+    n = na = 0
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        # keep stream B full for the whole burst of victim launches: ~40 aggressor kernels of 50-400 us beside 400 victim
+        # launches (+ their compare kernels) of ~15 us
+        with torch.cuda.stream(sb):
+            for _ in range(40):
+                fn()
+        with torch.cuda.stream(sa):
+            for _ in range(400):
+                out = sp.logmel_segments(audio, out_bf16=True)
+                nbad += (out != ref).any()
+        n += 400
+        na += 40
+        sa.synchronize()
+        sb.synchronize()
+    return n, int(nbad.item()), na
 
 
 
@@ -109,7 +148,17 @@ def victim(seconds, shift_gb=0):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "--aggressor":
+    if sys.argv[1] == "--inprocess":
+        secs = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
+        fams = sys.argv[3].split(",") if len(sys.argv) > 3 else FAMILIES
+        tot = 0
+        for fam in fams:
+            n, bad, na = inprocess(fam, secs)
+            tot += n
+            print("== one process, stream B = %-18s victim (stream A): %d log-mel launches, %d with a wrong frame; %d aggressor launches"
+                  % (fam, n, bad, na), flush=True)
+        print("total victim launches: %d" % tot)
+    elif sys.argv[1] == "--aggressor":
         aggressor(sys.argv[2], float(sys.argv[3]))
     elif sys.argv[1] == "--victim":
         victim(float(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 0)

@@ -36,13 +36,13 @@ def _free_port():
     return p
 
 
-def _batch(rank, B=2):
+def _batch(rank, B=2, Ld=128):
     """(log-mel [B, 256, 512] bf16 as a CPU tensor, labels): the mel is made here, in the calling process, on the GPU."""
     from contrib import spectrograms as sp
     from mrmt3.synthetic import synth_audio, synth_labels
     audio = torch.from_numpy(synth_audio(B, seed=50 + rank)).cuda()
     mel = sp.logmel_segments(audio, out_bf16=True)
-    return mel.cpu(), torch.from_numpy(synth_labels(B, 128, seed=60 + rank))
+    return mel.cpu(), torch.from_numpy(synth_labels(B, Ld, seed=60 + rank))
 
 
 def _model(dev):
@@ -69,23 +69,26 @@ def _worker(rank, world, port, q, batch, steps=1, graph=False):
                 m.flat.P.mul_(1.5)                       # the trainer's initial broadcast must undo this
         tr = Trainer(m, lr=1e-3, graph=graph)
         mel, lab = batch
+        from mrmt3 import lib
+        lib.dispatch_counts(reset=True)
         for _ in range(steps):
             loss = tr.train_step(mel.to(dev), lab.to(dev), audio=False)
         torch.cuda.synchronize()
+        counts = lib.dispatch_counts()
         assert tr.graph_captured == (graph and steps > 2)
         if tr.graph_captured:       # one graph per gradient bucket, the collectives stay eager between the replays
             cap = next(iter(tr._graphs.values()))
             assert len(cap.segments) == len(tr.buckets.buckets) >= 4
-        q.put((rank, m.flat.G.cpu().numpy(), m.flat.P.cpu().numpy(), float(loss.item())))
+        q.put((rank, m.flat.G.cpu().numpy(), m.flat.P.cpu().numpy(), float(loss.item()), counts, len(tr.buckets.buckets)))
     finally:
         dist.destroy_process_group()
 
 
-def _run_two_ranks(steps=1, graph=False):
+def _run_two_ranks(steps=1, graph=False, B=2, Ld=128, with_counts=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    batches = [_batch(r) for r in range(2)]          # log-mel computed here, before the ranks share the GPU
+    batches = [_batch(r, B, Ld) for r in range(2)]   # log-mel computed here, before the ranks share the GPU
     torch.cuda.synchronize()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, batches[r], steps, graph)) for r in range(2)]
     for p in procs:
@@ -94,7 +97,7 @@ def _run_two_ranks(steps=1, graph=False):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    return res
+    return res if with_counts else [r[:4] for r in res]
 
 
 def test_two_ranks_segmented_graph_replay_equals_eager():
@@ -134,6 +137,38 @@ def test_two_ranks_match_one_process_on_the_global_batch():
     assert abs(loss.item() - l0) < 2e-3
     dp = np.abs(p0 - m.flat.P.cpu().numpy()).max()
     assert dp < 2.5e-3, dp                                          # one AdamW step of lr 1e-3 moves a weight by <= ~1e-3
+
+
+def test_two_ranks_at_the_big_kernels_match_one_process_on_the_global_batch():
+    """the same comparison with 16 x 256 tokens per rank — 4096 decoder (and encoder) rows, where the
+    ping-pong NT kernel, the fused wi + GEGLU launch (from 4096 rows), the fused data-gradient + row kernels and the grouped
+    weight-gradient launch (one per gradient bucket) all dispatch under two ranks; asserted through
+    mrmt3_dispatch_counts.  Mel fed from the parent."""
+    assert torch.cuda.is_available()
+    res = _run_two_ranks(B=16, Ld=256, with_counts=True)
+    (_, g0, p0, l0, c0, nb0), (_, g1, p1, l1, c1, nb1) = res
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)
+    assert abs(l0 - l1) < 1e-6
+    for c, nb in ((c0, nb0), (c1, nb1)):
+        assert c["gemm_nt8"] >= 40, c                 # decoder forward + data-gradient products on the ping-pong kernel
+        assert c["gemm_nt_geglu"] >= 16, c            # fused wi + GEGLU launches of both stacks
+        assert c["tn_group"] >= nb - 1 >= 3, (c, nb)  # one grouped weight-gradient launch per bucket with gradients due
+        assert c["gemm_nt_geglubwd"] >= 8 and c["gemm_nt_normbwd"] >= 8, c
+
+    from mrmt3.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    m = _model(dev)
+    tr = Trainer(m, lr=1e-3, graph=False)
+    a0, t0 = _batch(0, 16, 256)
+    a1, t1 = _batch(1, 16, 256)
+    loss = tr.train_step(torch.cat([a0, a1]).to(dev), torch.cat([t0, t1]).to(dev), audio=False)
+    torch.cuda.synchronize()
+    g = m.flat.G.cpu().numpy()
+    rel = np.linalg.norm(g0 / 2 - g) / np.linalg.norm(g)
+    assert rel < 2e-2, rel
+    assert abs(loss.item() - l0) < 2e-3
+    dp = np.abs(p0 - m.flat.P.cpu().numpy()).max()
+    assert dp < 2.5e-3, dp
 
 
 def _dropin_worker(rank, world, port, q, batch):

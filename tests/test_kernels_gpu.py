@@ -67,6 +67,45 @@ def test_logmel_edge_cases(dev):
     np.testing.assert_allclose(gb, logmel_ref.logmel_segments(x[:, :32768]), atol=4e-3, rtol=0)
 
 
+def test_logmel_wave_kernel_matches_the_round1_kernel(dev, monkeypatch):
+    """Round 4's wave-per-frame kernel (64 frames per workgroup, a 16 x 16 x 4 FFT in registers, csrc/logmel.hip) against
+    round 1's workgroup-per-frame kernel (MRMT3_LOGMEL=0): two independent implementations of the same transform
+    (contrib/spectrograms.py:128-145) agree to f32 FFT rounding on ragged lengths, frame counts off the 64-frame grid,
+    padded frames, bf16 output and crops at odd sample offsets; the mel sums and the scaling are the same arithmetic."""
+    from contrib import spectrograms as sp
+    rs = np.random.RandomState(11)
+    for B, n in ((2, 32768), (1, 40000), (3, 128 * 70 + 5), (1, 2048), (1, 300), (5, 128 * 129)):
+        x = torch.from_numpy((rs.uniform(-1, 1, size=(B, n)) * rs.uniform(0.01, 1.0, size=(B, 1))).astype(np.float32)).to(dev)
+        vf = torch.tensor([max(1, (n // 128) // (b + 2)) for b in range(B)], dtype=torch.int32, device=dev)
+        for kw in (dict(), dict(valid_frames=vf), dict(normalize=False), dict(out_bf16=True)):
+            monkeypatch.setenv("MRMT3_LOGMEL", "0")
+            old = sp.logmel_segments(x, **kw).float()
+            monkeypatch.setenv("MRMT3_LOGMEL", "1")
+            new = sp.logmel_segments(x, **kw).float()
+            assert new.shape == old.shape
+            tol = 4e-3 if kw.get("out_bf16") else (2e-4 if kw.get("normalize", True) else 3e-3)
+            # un-normalised: log of near-cancelled bins amplifies the FFT's rounding; bound where the energy is
+            d = (new - old).abs()
+            if kw.get("normalize", True):
+                assert d.max().item() <= tol, (B, n, kw, d.max().item())
+            else:
+                big = old > old.max() - 10.0
+                assert d[big].max().item() <= tol, (B, n, kw, d[big].max().item())
+            if "valid_frames" in kw:
+                for b in range(B):
+                    assert (new[b, int(vf[b]):] == 0).all()
+    # crops out of one recording at odd sample offsets
+    song = torch.from_numpy(rs.uniform(-1, 1, size=128 * 700 + 77).astype(np.float32)).to(dev)
+    starts = torch.tensor([0, 13, 255, 600], dtype=torch.int64)
+    vfc = torch.tensor([256, 200, 256, 64], dtype=torch.int32)
+    monkeypatch.setenv("MRMT3_LOGMEL", "0")
+    old = sp.logmel_crops(song, starts, 256, valid_frames=vfc)
+    monkeypatch.setenv("MRMT3_LOGMEL", "1")
+    new = sp.logmel_crops(song, starts, 256, valid_frames=vfc)
+    assert (new - old).abs().max().item() <= 2e-4
+    assert (new[1, 200:] == 0).all() and (new[3, 64:] == 0).all()
+
+
 # ---- GEMMs ------------------------------------------------------------------------------------------
 
 def test_logmel_crops_of_one_recording(dev):
