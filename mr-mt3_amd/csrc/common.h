@@ -118,17 +118,24 @@ __host__ inline DropCfg make_drop(float p, unsigned long long seed, unsigned str
 // tanh(u) = 1 - 2 / (exp(2u) + 1): one v_exp_f32 and one v_rcp_f32 instead of libm's branchy tanhf (~3x the
 // instructions; with the activations served from the Infinity Cache the GEGLU kernels were as much VALU as memory).
 // Saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1); absolute error <= 2e-7.
+// (#pragma clang fp contract(off) inside the activation helpers and at the top of rowops.hip / gemm_rows.hip: the fused
+// kernels promise the SAME BITS as the element-wise kernels they replace, and which a * b + c becomes an FMA is otherwise the
+// compiler's choice per call site — it differed between the two files as soon as the build flags changed.  Where an FMA is
+// wanted it is written as fmaf.)
 __device__ __forceinline__ float fast_tanh(float u) {
+#pragma clang fp contract(off)
   const float e = __builtin_amdgcn_exp2f(u * 2.885390081777927f);   // exp(2u)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ float gelu_new_f(float x) {
+#pragma clang fp contract(off)
   const float c = 0.7978845608028654f;  // sqrt(2/pi)
   return 0.5f * x * (1.0f + fast_tanh(c * (x + 0.044715f * (x * x * x))));
 }
 
 // gelu_new and its derivative (HF NewGELUActivation; the GEGLU backward, element-wise kernel and GEMM epilogue alike)
 __device__ __forceinline__ void gelu_new_fd(float x, float* f, float* d) {
+#pragma clang fp contract(off)
   const float c = 0.7978845608028654f;
   const float t = fast_tanh(c * (x + 0.044715f * (x * x * x)));
   *f = 0.5f * x * (1.0f + t);

@@ -33,6 +33,9 @@
 
 #include "common.h"
 
+// no implicit FMA formation: the row phases restate rowops.hip's arithmetic and must land on the same bits
+#pragma clang fp contract(off)
+
 #define GR_OOB 0x7FFF0000
 #define GR_YLD 1040                       // bytes per row of the LDS image of the output tile
 #define GR_B_BYTES 65536                  // 8 waves x 2 slots x 4 KiB of private weight rows
@@ -74,6 +77,13 @@ __device__ __forceinline__ void gr_dma16(__amdgpu_buffer_rsrc_t r, unsigned char
 }
 #define GR_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// The lane's two 8-byte pieces of an image row (columns 4 lane .. + 3 and 256 + 4 lane .. + 3, 512 bytes apart) in ONE
+// ds_read2st64_b64.
+__device__ __forceinline__ u32x4 gr_img_pair(const unsigned char* p) {
+  u32x4 r;
+  asm volatile("ds_read2st64_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((unsigned)(uintptr_t)p) : "memory");
+  return r;
+}
 __device__ __forceinline__ void gr_unpack4(u32x2 t, float v[4]) {
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
   v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
@@ -169,7 +179,8 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
   auto ldA = [&](int slot, int chunk) __attribute__((always_inline)) {
     const bool on = chunk < np && !(P.dbg & 32);
 #pragma unroll
-    for (int q = 0; q < NAP; ++q) gr_dma16(ra, ldsA + slot * A_SLOT + q * 8192, voffA, on ? koff(chunk) + q * astride : GR_OOB);
+    for (int q = 0; q < NAP; ++q)
+      gr_dma16(ra, ldsA + slot * A_SLOT + q * 8192, voffA, on ? koff(chunk) + q * astride : GR_OOB);
   };
   // B of K chunk `chunk` (64 deep), column half ch -> this wave's slot ch
   auto ldB = [&](int ch, int chunk) __attribute__((always_inline)) {
@@ -272,6 +283,10 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
 #pragma unroll
     for (int i = 0; i < 2; ++i) gr_load4<false>(P.wn, i * 256 + lane * 4, wv[i]);
     constexpr int G = RPW;                       // rows per group: all of the wave's rows (8 or 16)
+    // the wave's pieces of the tile image first (LDS reads while none of this wave's global loads are in flight)
+    u32x4 yimg[G];
+#pragma unroll
+    for (int t = 0; t < G; ++t) yimg[t] = gr_img_pair(lds + (w + 8 * t) * GR_YLD + lane * 8);
     f32x4 xv[G][2];
 #pragma unroll
     for (int t = 0; t < G; ++t) {
@@ -289,12 +304,13 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
       ss[t] = 0.f;
       if (row >= P.M) continue;
       const size_t base = (size_t)row * 512;
+      const u32x4 y4 = yimg[t];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int col = i * 256 + lane * 4;
         float v[4] = {xv[t][i].x, xv[t][i].y, xv[t][i].z, xv[t][i].w};
         float yv[4];
-        gr_unpack4(*(const u32x2*)(lds + lr * GR_YLD + col * 2), yv);
+        gr_unpack4(i == 0 ? u32x2{y4.x, y4.y} : u32x2{y4.z, y4.w}, yv);
         if (dy.thresh) {
           float m[4];
           drop_mask4(dy, (base + col) >> 2, m);
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
           else *(f32x4*)(P.x1 + base + col) = xv[t][i];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ss[t] += v[e] * v[e];
+        for (int e = 0; e < 4; ++e) ss[t] = fmaf(v[e], v[e], ss[t]);
       }
     }
     // wave_sum of every row, the rows' butterflies interleaved (per row: the same six steps in the same order)
@@ -377,17 +393,17 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
         dot[t] = 0.f;
         if (row >= P.M) continue;
         const float rstd = rs[t];
+        const u32x4 g4 = gr_img_pair(lds + lr * GR_YLD + lane * 8);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int col = i * 256 + lane * 4;
-          gr_unpack4(*(const u32x2*)(lds + lr * GR_YLD + col * 2), g[t][i]);
+          gr_unpack4(i == 0 ? u32x2{g4.x, g4.y} : u32x2{g4.z, g4.w}, g[t][i]);
           float xh[4] = {xv[t][i].x, xv[t][i].y, xv[t][i].z, xv[t][i].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             xh[e] *= rstd;
-            dwp[i][e] += g[t][i][e] * xh[e];
+            dwp[i][e] = fmaf(g[t][i][e], xh[e], dwp[i][e]);
             g[t][i][e] *= wv[i][e];
-            dot[t] += g[t][i][e] * xh[e];
+            dot[t] = fmaf(g[t][i][e], xh[e], dot[t]);
           }
           xv[t][i] = f32x4{xh[0], xh[1], xh[2], xh[3]};
         }
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
           const float xh[4] = {xv[t][i].x, xv[t][i].y, xv[t][i].z, xv[t][i].w};
           float d[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) d[e] = rstd * (g[t][i][e] - xh[e] * dt);
+          for (int e = 0; e < 4; ++e) d[e] = rstd * fmaf(-xh[e], dt, g[t][i][e]);
           float rv[4];
           if constexpr (RI) gr_unpack4(rr[t][i], rv);
           else { rv[0] = rr[t][i].x; rv[1] = rr[t][i].y; rv[2] = rr[t][i].z; rv[3] = rr[t][i].w; }

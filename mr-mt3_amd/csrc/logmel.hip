@@ -164,11 +164,12 @@ __global__ __launch_bounds__(LM_THREADS) void logmel_kernel(
 //   * the unpack to the 1025 real-input bins, the magnitudes, the sparse mel sums (8 consecutive mel bins per lane, the
 //     taps in the old kernel's order: same mel arithmetic), log and scaling follow in the same wave, and a frame leaves
 //     as one 16-byte store per lane (bf16).
-// The workgroup's static LDS is the CU's whole 160 KB on purpose: profiles/r04_one_process_two_stream_soak.txt shows
-// that the old kernel's plain LDS FFT came out wrong (one workgroup in ~10) whenever workgroups of the flash-attention /
-// round-1 tile kernels shared its CU — from another stream of the SAME process as much as from another process — while
-// kernels that own a CU never disturbed it or were disturbed.  With all of the LDS taken no LDS-using kernel can be its
-// co-tenant.
+// The workgroup's static LDS is the CU's whole 160 KB: profiles/r04_one_process_two_stream_soak.txt shows the old kernel
+// coming out wrong (one launch in ~8) whenever workgroups of the flash-attention / round-1 tile kernels shared its CU — from
+// another stream of the SAME process as much as from another process.  With all of the LDS taken no such kernel can be its
+// co-tenant.  (Later in round 4 the fault itself was traced to packed f32 VALU instructions, which the library no longer
+// contains — profiles/r04_lds_read_fault.txt, csrc/Makefile — so the old kernel is clean too; the exclusive request stays
+// as a second line of defence and costs nothing: one 8-wave workgroup per CU is this kernel's shape anyway.)
 #define LMW_WAVES 8
 #define LMW_THREADS (LMW_WAVES * 64)
 #define LMW_STRIP_FLOATS 10112                 // (64 - 1) * 128 + 2048

@@ -7,6 +7,9 @@
 // entry point.
 #include "common.h"
 
+// no implicit FMA formation in this file: gemm_rows.hip restates these kernels' arithmetic and must land on the same bits
+#pragma clang fp contract(off)
+
 template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
   f32x4 t = *(const f32x4*)p;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const float* __res
         else store4<float>(x1 + base + col, v[i]);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ss += v[i][e] * v[i][e];
+      for (int e = 0; e < 4; ++e) ss = fmaf(v[i][e], v[i][e], ss);
     }
   }
   ss = wave_sum(ss);
@@ -211,9 +214,9 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[i][e] *= rstd;
-          dwp[i][e] += g[i][e] * xh[i][e];
+          dwp[i][e] = fmaf(g[i][e], xh[i][e], dwp[i][e]);
           g[i][e] *= wv[i][e];
-          dot += g[i][e] * xh[i][e];
+          dot = fmaf(g[i][e], xh[i][e], dot);
         }
       }
     }
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_bwd_kernel(const TG* __restri
         const int col = i * 256 + lane * 4;
         float d[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = rstd * (g[i][e] - xh[i][e] * dot);
+        for (int e = 0; e < 4; ++e) d[e] = rstd * fmaf(-xh[i][e], dot, g[i][e]);
         if (dres != nullptr) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) d[e] += rr[i][e];
