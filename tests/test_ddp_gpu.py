@@ -8,13 +8,12 @@ RCCL) against ONE process that sees both ranks' segments:
   * the side-stream weight gradients are joined before their bucket is exchanged (a missed join shows up as a
     mismatch here).
 
-The ranks are fed the log-mel INPUT, computed once in this (parent) process before they start, not raw audio: two
-processes sharing one GPU is a configuration of this file only, and round 3 found that under it the log-mel kernel — a
-plain LDS FFT — is occasionally computed wrongly when workgroups of the OTHER process's LDS-DMA + MFMA kernels share its
-CU (profiles/r03_two_process_soak.txt: reproduced with a 60-line stand-alone FFT; not gloo, not the side stream, not the
-hand-offs; a lone process is bitwise repeatable).  That was the "1 in 40" mismatch round 2 retried on; with the frontend
-out of the two-process region the comparisons below hold on the first try (100 soak repetitions: 0 differences).  The
-frontend inside the training step is covered single-process (test_train_graph_gpu.py, test_train_infer_gpu.py).
+Most tests here feed the ranks the log-mel INPUT, computed once in this (parent) process: rounds 2-3 saw "1 in 40" runs diverge
+when two processes shared the GPU and traced it to the log-mel kernel coming out wrong beside the other process's LDS-DMA +
+MFMA kernels (profiles/r03_two_process_soak.txt).  Round 4 found the cause — packed f32 VALU instructions emitted by the
+compiler's SLP vectoriser misbehave when such kernels share the CU, from another stream of one process as well
+(profiles/r04_lds_read_fault.txt) — and builds the library without them; test_two_ranks_with_the_frontend_inside_the_step…
+now runs the once-failing configuration (raw audio in, both ranks on one GPU) and asserts bitwise repeatability.
 """
 import os
 import socket
@@ -51,7 +50,7 @@ def _model(dev):
     return T5ForConditionalGeneration(dict(T5_SMALL, dropout_rate=0.0)).load_golden().to(dev)
 
 
-def _worker(rank, world, port, q, batch, steps=1, graph=False):
+def _worker(rank, world, port, q, batch, steps=1, graph=False, audio=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "mr-mt3_amd")):
@@ -72,7 +71,7 @@ def _worker(rank, world, port, q, batch, steps=1, graph=False):
         from mrmt3 import lib
         lib.dispatch_counts(reset=True)
         for _ in range(steps):
-            loss = tr.train_step(mel.to(dev), lab.to(dev), audio=False)
+            loss = tr.train_step(mel.to(dev), lab.to(dev), audio=audio)
         torch.cuda.synchronize()
         counts = lib.dispatch_counts()
         assert tr.graph_captured == (graph and steps > 2)
@@ -84,13 +83,21 @@ def _worker(rank, world, port, q, batch, steps=1, graph=False):
         dist.destroy_process_group()
 
 
-def _run_two_ranks(steps=1, graph=False, B=2, Ld=128, with_counts=False):
+def _audio_batch(rank, B=2, Ld=128):
+    """(raw audio [B, 32768] f32 as a CPU tensor, labels): the ranks run the log-mel frontend themselves."""
+    from mrmt3.synthetic import synth_audio, synth_labels
+    return torch.from_numpy(synth_audio(B, seed=50 + rank)), torch.from_numpy(synth_labels(B, Ld, seed=60 + rank))
+
+
+def _run_two_ranks(steps=1, graph=False, B=2, Ld=128, with_counts=False, audio=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    batches = [_batch(r, B, Ld) for r in range(2)]   # log-mel computed here, before the ranks share the GPU
+    # (audio=False: log-mel computed here, before the ranks share the GPU — how rounds 3-4 kept the frontend out of the
+    # two-process region while the co-residency fault was open)
+    batches = [(_audio_batch if audio else _batch)(r, B, Ld) for r in range(2)]
     torch.cuda.synchronize()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, batches[r], steps, graph)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, batches[r], steps, graph, audio)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
@@ -137,6 +144,21 @@ def test_two_ranks_match_one_process_on_the_global_batch():
     assert abs(loss.item() - l0) < 2e-3
     dp = np.abs(p0 - m.flat.P.cpu().numpy()).max()
     assert dp < 2.5e-3, dp                                          # one AdamW step of lr 1e-3 moves a weight by <= ~1e-3
+
+
+def test_two_ranks_with_the_frontend_inside_the_step_are_repeatable():
+    """The configuration that diverged "1 in 20" in rounds 2-3: two processes on one GPU, raw AUDIO in, the log-mel kernel
+    running beside the other rank's flash-attention / tile kernels.  Round 4 traced the fault to packed f32 VALU
+    instructions (profiles/r04_lds_read_fault.txt) and builds the library without them: three independent two-rank runs of
+    five steps (eager, then graph-replayed) land on the same bits, and both ranks hold identical replicas."""
+    assert torch.cuda.is_available()
+    runs = [_run_two_ranks(steps=5, graph=(i == 2), audio=True) for i in range(3)]
+    for res in runs:
+        (_, g0, p0, l0), (_, g1, p1, l1) = res
+        assert np.array_equal(g0, g1) and np.array_equal(p0, p1)
+    for res in runs[1:]:
+        for (r0, g0, p0, l0), (r1, g1, p1, l1) in zip(runs[0], res):
+            assert r0 == r1 and np.array_equal(g0, g1) and np.array_equal(p0, p1) and abs(l0 - l1) < 2e-6
 
 
 def test_two_ranks_at_the_big_kernels_match_one_process_on_the_global_batch():
