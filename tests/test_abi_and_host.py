@@ -4,6 +4,7 @@ harness restatement (hand-derived answers from inference.py:64-136,206-215)."""
 import ctypes
 import math
 import os
+import re
 
 import numpy as np
 import pytest
@@ -21,6 +22,32 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert set(names) == set(lib._SIGS), set(names) ^ set(lib._SIGS)
     assert lib.load().mrmt3_version() >= 100
+
+
+def test_device_code_has_no_packed_f32_instructions(tmp_path):
+    """The build contract of csrc/Makefile (`SLP_FLAG`): no `v_pk_{add,mul,fma}_f32` / `v_pk_mov_b32` in ANY code object of the
+    library.  On gfx950 a packed f32 instruction with a half swap returns a wrong low half in lanes 48-63 while an
+    LDS-DMA + MFMA kernel shares the CU (profiles/r04_lds_read_fault.txt) - the cause of the two-rank
+    and two-stream mismatches of rounds 2-3.  Also checks that the hot files are really there (MFMA counts)."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    so = str(tmp_path / "lib.so")
+    shutil.copy(lib.LIB_PATH, so)                      # --offloading extracts next to its input
+    subprocess.run([objdump, "--offloading", so], check=True, capture_output=True)
+    objs = sorted(str(f) for f in tmp_path.iterdir() if f.name.endswith("gfx950"))
+    assert len(objs) >= 10, objs
+    packed = re.compile(r"\bv_pk_(add|mul|fma)_f32\b|\bv_pk_mov_b32\b")
+    n_mfma = n_dma = 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+        hits = [l.strip() for l in asm.splitlines() if packed.search(l)]
+        assert not hits, (os.path.basename(o), hits[:3])
+        n_mfma += asm.count("v_mfma_f32_16x16x32_bf16")
+        n_dma += len(re.findall(r"buffer_load_dword(x[34])? .* lds", asm)) + asm.count("global_load_lds_dword")
+    assert n_mfma > 4000 and n_dma > 400, (n_mfma, n_dma)
 
 
 def test_product_path_refuses_cpu_tensors():
