@@ -18,8 +18,9 @@ for r in step:
     e[0] += 1
     e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 busy = sum(v[1] for v in agg.values())
-print("One replayed training step (B = 64, MT3Net, bf16, dropout on) from the rocprofv3 kernel trace of `python3 bench.py --steps 20 "
+batch = sys.argv[2] if len(sys.argv) > 2 else "64"          # optional second argument: the --batch the trace was taken at
+print("One replayed training step (B = %s, MT3Net, bf16, dropout on) from the rocprofv3 kernel trace of `python3 bench.py%s --steps 20 "
       "--warmup 5 --no-cpu-baseline --no-inference --extra-batch 0`, between two adamw_kernel launches: %d kernels, span %.3f ms, "
-      "kernel time %.3f ms\n" % (len(step), (t1 - t0) / 1e6, busy / 1e6))
+      "kernel time %.3f ms\n" % (batch, "" if batch == "64" else " --batch " + batch, len(step), (t1 - t0) / 1e6, busy / 1e6))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-72s %4d launches %8.3f ms %5.1f %%  avg %8.1f us" % (k, v[0], v[1] / 1e6, 100 * v[1] / busy, v[1] / v[0] / 1e3))
