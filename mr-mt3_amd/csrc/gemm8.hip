@@ -59,7 +59,7 @@ struct G8Params {
   int ksplit, mpad, kfull;
   int nt_c;            // 1: streaming (non-temporal) C stores; bit 1 (EPI = 1): also for g.  See g8_store_mode().
   int dbg;             // diagnostics (MRMT3_GEMM8_DBG): 1 no C stores, 2 plain instead of streaming C stores (bf16), 4 every K step re-reads K step 0 (cache-hot),
-                       // 8 no fragment reads, 16 loads switched off (zero fill, no traffic)
+                       // 8 no fragment reads, 16 loads switched off (zero fill, no traffic); EPI = 1 only: 64 no h stores, 128 no g stores
   int skew_ticks;      // start delay per (slot % 8), in 10-ns ticks of s_memrealtime (see the kernel)
 };
 
@@ -338,11 +338,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
         }
         if (row < P.M) {
           bf16_t* hp = (bf16_t*)P.C + (size_t)row * P.ldc + f0;
-          __builtin_nontemporal_store((u32x4{h0p[0], h0p[1], h0p[2], h0p[3]}), (u32x4*)hp);
-          __builtin_nontemporal_store((u32x4{h1p[0], h1p[1], h1p[2], h1p[3]}), (u32x4*)(hp + P.dff));
+          if (!(P.dbg & 64)) {
+            __builtin_nontemporal_store((u32x4{h0p[0], h0p[1], h0p[2], h0p[3]}), (u32x4*)hp);
+            __builtin_nontemporal_store((u32x4{h1p[0], h1p[1], h1p[2], h1p[3]}), (u32x4*)(hp + P.dff));
+          }
           const u32x4 gv = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
           u32x4* gp = (u32x4*)((bf16_t*)P.C2 + (size_t)row * P.ldc2 + f0);
-          if (P.nt_c & 2) __builtin_nontemporal_store(gv, gp);      // (h: only the backward reads it again; g: the next kernel)
+          if (P.dbg & 128) {}
+          else if (P.nt_c & 2) __builtin_nontemporal_store(gv, gp);      // (h: only the backward reads it again; g: the next kernel)
           else *gp = gv;
         }
       }
