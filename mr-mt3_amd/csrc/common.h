@@ -118,28 +118,36 @@ __host__ inline DropCfg make_drop(float p, unsigned long long seed, unsigned str
 // tanh(u) = 1 - 2 / (exp(2u) + 1): one v_exp_f32 and one v_rcp_f32 instead of libm's branchy tanhf (~3x the
 // instructions; with the activations served from the Infinity Cache the GEGLU kernels were as much VALU as memory).
 // Saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1); absolute error <= 2e-7.
-// (#pragma clang fp contract(off) inside the activation helpers and at the top of rowops.hip / gemm_rows.hip: the fused
-// kernels promise the SAME BITS as the element-wise kernels they replace, and which a * b + c becomes an FMA is otherwise the
-// compiler's choice per call site — it differed between the two files as soon as the build flags changed.  Where an FMA is
-// wanted it is written as fmaf.)
+// Every a * b + c of the activation helpers is an EXPLICIT fmaf and contraction is off around them (as it is at the top of
+// rowops.hip / gemm_rows.hip): the fused kernels promise the SAME BITS as the element-wise kernels they replace, and which
+// a * b + c becomes an FMA is otherwise the compiler's choice per call site — it differed between two files as soon as the
+// build flags changed.  Written out, the helpers are also shorter than what either setting gave: gelu_new 9 vector
+// instructions + v_exp + v_rcp (contraction off, no fmaf: 13 + 2), gelu_new with its derivative 17 + 2 (was 29 + 2); the
+// GEGLU epilogues are vector-issue time that nothing hides (profiles/r04_geglu_store_probe.txt).
 __device__ __forceinline__ float fast_tanh(float u) {
 #pragma clang fp contract(off)
   const float e = __builtin_amdgcn_exp2f(u * 2.885390081777927f);   // exp(2u)
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 __device__ __forceinline__ float gelu_new_f(float x) {
 #pragma clang fp contract(off)
   const float c = 0.7978845608028654f;  // sqrt(2/pi)
-  return 0.5f * x * (1.0f + fast_tanh(c * (x + 0.044715f * (x * x * x))));
+  const float t = fast_tanh(c * fmaf(0.044715f, x * x * x, x));
+  const float hx = 0.5f * x;
+  return fmaf(hx, t, hx);                                            // 0.5 x (1 + t)
 }
 
 // gelu_new and its derivative (HF NewGELUActivation; the GEGLU backward, element-wise kernel and GEMM epilogue alike)
 __device__ __forceinline__ void gelu_new_fd(float x, float* f, float* d) {
 #pragma clang fp contract(off)
   const float c = 0.7978845608028654f;
-  const float t = fast_tanh(c * (x + 0.044715f * (x * x * x)));
-  *f = 0.5f * x * (1.0f + t);
-  *d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+  const float x2 = x * x;
+  const float t = fast_tanh(c * fmaf(0.044715f, x2 * x, x));
+  const float hx = 0.5f * x;
+  *f = fmaf(hx, t, hx);
+  // d = 0.5 (1 + t) + 0.5 x (1 - t^2) c (1 + 3 * 0.044715 x^2)
+  const float p = fmaf(0.5f, t, 0.5f), q = fmaf(-t, t, 1.0f), w = fmaf(3.0f * 0.044715f, x2, 1.0f);
+  *d = fmaf(hx * q * c, w, p);
 }
 
 // norm-weight gradient: per-workgroup partial rows are summed by DW_CHUNKS row chunks (rowops.hip: dw_reduce_body);

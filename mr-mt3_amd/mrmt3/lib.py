@@ -126,7 +126,7 @@ def load():
     return lib
 
 
-MIN_VERSION = 105
+MIN_VERSION = 106
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
                  "gemm_nt_geglubwd")
