@@ -363,7 +363,8 @@ def main():
         "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
         "step_graph": bool(trainer.use_graph and trainer.graph_captured),
         "graph_segments": (len(next(iter(trainer._graphs.values())).segments) + 1) if trainer._graphs else 0,
-        "collectives": ("rccl, %d buckets per step%s" % (len(trainer.buckets.buckets), " (forced at world 1)" if force_coll and world == 1 else "")
+        "collectives": ("rccl%s, %d buckets per step%s" % (" through the C ABI (mrmt3_allreduce)" if trainer.buckets.native else " through torch.distributed",
+                                                           len(trainer.buckets.buckets), " (forced at world 1)" if force_coll and world == 1 else "")
                         if trainer.buckets.active else "none (world 1)"),
         # the grouped weight-gradient launch of the last join (with collectives: of the last gradient bucket)
         "weight_gradient_launch": (lambda g: None if g is None or g.last_info is None else

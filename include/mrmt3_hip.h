@@ -39,6 +39,7 @@ extern "C" {
 #define MRMT3_ERR_INVALID_ARG 1
 #define MRMT3_ERR_HIP 2
 #define MRMT3_ERR_UNSUPPORTED 3
+#define MRMT3_ERR_COMM 4          /* RCCL missing or a collective call failed */
 
 #define MRMT3_F32 0
 #define MRMT3_BF16 1
@@ -410,6 +411,25 @@ int mrmt3_decoder_graph_captured(const mrmt3_decoder* dec);
  * which the last row finished (or -1); [0] counts prefix positions too, [2] counts token steps only.  Copies 3 int32 asynchronously to caller-owned PINNED host
  * memory; the caller synchronises the stream before reading. */
 int mrmt3_decoder_poll(mrmt3_decoder* dec, int32_t* state_out_pinned, void* stream);
+
+/* ---- gradient exchange (data parallel, one process per GPU): RCCL communicators as opaque handles ----------------
+ * Replaces what the reference gets from Lightning's `ddp_find_unused_parameters_false` strategy (config/config.yaml:45,
+ * train.sh:6): torch DDP's bucketed NCCL all-reduce of the gradients.  The flat f32 gradient buffer is exchanged as a few
+ * contiguous buckets (mrmt3/ddp.py), each with one in-place all-reduce on a stream of the caller's choosing.
+ * RCCL is resolved at first use (dlopen: $MRMT3_RCCL_LIB, an already mapped librccl, the loader's path, /opt/rocm/lib);
+ * the library itself does not link against it.
+ *   mrmt3_comm_unique_id : rank 0 fills id_out[MRMT3_COMM_ID_BYTES] and hands the bytes to every other rank (any channel).
+ *   mrmt3_comm_create    : every rank, same id; blocks until all `world` ranks have called it.  The GPU the communicator
+ *                          is bound to is the calling thread's current HIP device.
+ *   mrmt3_allreduce      : buf[0..count) (dtype MRMT3_F32 or MRMT3_BF16, device memory) = sum over ranks, or the mean when
+ *                          average != 0; in place, asynchronous on `stream`; every rank must call it with the same count,
+ *                          dtype and order of calls.
+ *   mrmt3_comm_destroy   : releases the handle (NULL is accepted). */
+#define MRMT3_COMM_ID_BYTES 128
+int mrmt3_comm_unique_id(void* id_out);
+int mrmt3_comm_create(const void* id, int rank, int world, void** comm_out);
+int mrmt3_comm_destroy(void* comm);
+int mrmt3_allreduce(void* comm, void* buf, size_t count, int dtype, int average, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ void mrmt3_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int mrmt3_version(void) { return 106; /* 0.1.6: round 4 (gemm_rows: projection + row kernel in one launch; 106: activation helpers as explicit FMAs) */ }
+extern "C" int mrmt3_version(void) { return 107; /* 0.1.7: round 4 (gemm_rows: projection + row kernel in one launch; 106: activation helpers as explicit FMAs; 107: mrmt3_comm_*, mrmt3_allreduce) */ }
 extern "C" const char* mrmt3_last_error(void) { return g_err; }
 
 // Page-locked host memory for tables the device reads through an async copy (the grouped weight-gradient plan): owned by

@@ -55,6 +55,17 @@ class _Widen:
         self.grad.copy_(self.low)
 
 
+class _StreamWork:
+    """A collective enqueued on the launch stream through the C ABI (MRMT3_DDP_NATIVE=1): wait() = the current stream
+    waits for it (what torch's Work.wait() does for an RCCL collective: a stream-level wait, nothing on the host)."""
+
+    def __init__(self, event, device):
+        self.event, self.device = event, device
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+
+
 class GradBuckets:
     """Partition of the flat gradient buffer into buckets ordered by when backward completes them."""
 
@@ -117,6 +128,10 @@ class GradBuckets:
         self._launch = None
         # single-GPU check of the collective path (profiles/tools/nccl_one_rank_check.py): run the all-reduces at world 1
         self.force = os.environ.get("MRMT3_DDP_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
+        # MRMT3_DDP_NATIVE=1: the buckets of GPU gradients go through the C ABI (mrmt3_allreduce on an RCCL communicator of the
+        # library's own, csrc/comm.hip) instead of torch.distributed; torch.distributed only carries the 128-byte id once
+        self.native = os.environ.get("MRMT3_DDP_NATIVE") == "1"
+        self._comm = None
 
     def reset(self):
         self._works, self._fired = [], set()
@@ -138,6 +153,42 @@ class GradBuckets:
             w.wait()
         self._works = []
 
+    def _native_comm(self):
+        if self._comm is None:
+            from . import lib
+            rank = dist.get_rank(self.group)
+            box = [lib.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0 if self.group is None else dist.get_global_rank(self.group, 0), group=self.group)
+            self._comm = lib.Comm(box[0], rank, self.world)
+        return self._comm
+
+    def _all_reduce(self, t, stream=None):
+        """Enqueue the in-place sum of `t` over the ranks (on `stream`, default the current one); returns its Work."""
+        if self.native and t.is_cuda:
+            s = stream
+            if s is None:       # never on the compute stream itself: the collective overlaps what backward enqueues next
+                s = self._launch_stream(t.device)
+                s.wait_stream(torch.cuda.current_stream(t.device))
+            self._native_comm().allreduce(t, stream=s)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            return _StreamWork(ev, t.device)
+        if stream is None:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        with torch.cuda.stream(stream):
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _launch_stream(self, device):
+        if self._launch is None or self._launch.device != device:
+            self._launch = torch.cuda.Stream(device=device)
+        return self._launch
+
+    def close(self):
+        """Release the library's communicator (native path); the buckets stay usable — the next exchange makes a new one."""
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+
     def _fire(self, idx):
         if idx in self._fired:
             return
@@ -152,15 +203,13 @@ class GradBuckets:
             return self._fire_compressed(b, grad)
         extra = [s for s in (self.producer_streams() if self.producer_streams is not None else []) if s is not None]
         if grad.is_cuda and extra:
-            if self._launch is None or self._launch.device != grad.device:
-                self._launch = torch.cuda.Stream(device=grad.device)
-            self._launch.wait_stream(torch.cuda.current_stream(grad.device))
+            launch = self._launch_stream(grad.device)
+            launch.wait_stream(torch.cuda.current_stream(grad.device))
             for s in extra:
-                self._launch.wait_stream(s)
-            with torch.cuda.stream(self._launch):
-                self._works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                launch.wait_stream(s)
+            self._works.append(self._all_reduce(grad, launch))
         else:
-            self._works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(self._all_reduce(grad))
 
     def _fire_compressed(self, b, grad):
         """Round the bucket to the exchange dtype, all-reduce that copy, widen it back into the f32 gradient when the
@@ -173,8 +222,7 @@ class GradBuckets:
             self._staging = torch.empty(self.flat.numel, dtype=self.exchange_dtype, device=grad.device)
         low = self._staging[b["start"]:b["end"]]
         low.copy_(grad)
-        work = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._works.append(_Widen(work, low, grad))
+        self._works.append(_Widen(self._all_reduce(low), low, grad))
 
     def on_layer_done(self, prefix, i):
         """Engine callback: every gradient of `prefix` layer i (and above) is final."""

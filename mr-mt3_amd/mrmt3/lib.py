@@ -84,6 +84,10 @@ _SIGS = {
     "mrmt3_decoder_graph_captured": (ci, [vp]),
     "mrmt3_decoder_run": (ci, [vp, ci, vp]),
     "mrmt3_decoder_poll": (ci, [vp, vp, vp]),
+    "mrmt3_comm_unique_id": (ci, [vp]),
+    "mrmt3_comm_create": (ci, [vp, ci, ci, C.POINTER(vp)]),
+    "mrmt3_comm_destroy": (ci, [vp]),
+    "mrmt3_allreduce": (ci, [vp, vp, csz, ci, ci, vp]),
 }
 
 
@@ -126,7 +130,7 @@ def load():
     return lib
 
 
-MIN_VERSION = 106
+MIN_VERSION = 107
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
                  "gemm_nt_geglubwd")
@@ -899,3 +903,39 @@ def transpose_batched(src_flat, dst_flat, desc_table, tile_start, n_mats, total_
     _dev(src_flat, dst_flat, desc_table, tile_start)
     _check(load().mrmt3_transpose_batched(_p(src_flat), _p(dst_flat), _p(desc_table), _p(tile_start), n_mats,
                                           total_tiles, _stream()), "transpose_batched")
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """An RCCL communicator behind the C ABI (`mrmt3_comm_*`, `mrmt3_allreduce`): the gradient exchange of the data-parallel
+    step without torch.distributed in the data path (mrmt3/ddp.py, MRMT3_DDP_NATIVE=1).  `uid` = the 128 bytes rank 0 got from
+    `Comm.unique_id()`, handed to the other ranks by whatever channel the host has (ddp.py: one broadcast_object_list).
+    Creation blocks until every rank has created its end."""
+
+    def __init__(self, uid: bytes, rank: int, world: int):
+        assert len(uid) == COMM_ID_BYTES
+        self.rank, self.world = rank, world
+        self._h = vp()
+        buf = C.create_string_buffer(uid, COMM_ID_BYTES)
+        _check(load().mrmt3_comm_create(buf, rank, world, C.byref(self._h)), "comm_create")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(load().mrmt3_comm_unique_id(buf), "comm_unique_id")
+        return buf.raw
+
+    def allreduce(self, t: torch.Tensor, average: bool = False, stream=None):
+        """In place, asynchronous on `stream` (default: the current stream): t = sum (or mean) of t over the ranks."""
+        _dev(t)
+        assert t.is_contiguous()
+        s = C.c_void_p((stream or torch.cuda.current_stream(t.device)).cuda_stream)
+        _check(load().mrmt3_allreduce(self._h, _p(t), t.numel(), _dt(t), int(average), s), "allreduce")
+        return t
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, vp()
+            _check(load().mrmt3_comm_destroy(h), "comm_destroy")

@@ -193,6 +193,68 @@ def test_bucketed_step_with_grouped_weight_gradients_captures_and_equals_eager(d
         dist.destroy_process_group()
 
 
+def test_comm_abi_allreduce_at_world_one(dev):
+    """`mrmt3_comm_*` / `mrmt3_allreduce` (csrc/comm.hip: RCCL resolved with dlopen, no link-time dependency): a communicator
+    of one rank — the only size a one-GPU box can form — sums and averages in place, f32 and bf16, on a side stream;
+    argument errors come back as error codes with a message, not as aborts."""
+    from mrmt3 import lib
+    uid = lib.Comm.unique_id()
+    assert len(uid) == lib.COMM_ID_BYTES and any(uid)
+    comm = lib.Comm(uid, 0, 1)
+    try:
+        side = torch.cuda.Stream()
+        for dtype in (torch.float32, torch.bfloat16):
+            x = torch.randn(1 << 20, device=dev).to(dtype)
+            for average in (False, True):
+                y = x.clone()
+                side.wait_stream(torch.cuda.current_stream())
+                comm.allreduce(y, average=average, stream=side)
+                side.synchronize()
+                assert torch.equal(y, x)
+        comm.allreduce(torch.empty(0, device=dev))                      # nothing to do, no error
+        with pytest.raises(RuntimeError, match="no CPU fallback|device"):
+            comm.allreduce(torch.zeros(4))
+        rc = lib.load().mrmt3_allreduce(comm._h, None, 4, 7, 0, None)
+        assert rc != 0 and b"allreduce" in lib.load().mrmt3_last_error()
+    finally:
+        comm.close()
+    comm.close()                                                        # idempotent
+    with pytest.raises(RuntimeError, match="comm_create"):
+        lib.Comm(uid, 3, 2)
+
+
+def test_native_bucket_exchange_equals_the_torch_distributed_one(dev, monkeypatch):
+    """MRMT3_DDP_NATIVE=1: the gradient buckets of the replayed step go through the library's own RCCL communicator
+    (`mrmt3_allreduce` on the launch stream, one call per graph segment) instead of torch.distributed.  One rank with the
+    collectives forced (every bucket is really enqueued): losses and weights equal the torch.distributed run bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from mrmt3.trainer import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("MRMT3_DDP_FORCE_COLLECTIVES", "1")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        data = _batches(dev, 2, B=8, L=256)
+        runs = {}
+        for native in (False, True):
+            monkeypatch.setenv("MRMT3_DDP_NATIVE", "1" if native else "0")
+            m = _model("t5", dev)
+            tr = Trainer(m, lr=1e-3, graph=True)
+            assert tr.buckets.active and tr.buckets.native == native
+            losses = [float(tr.train_step(*data[i % 2][:2], audio=True).item()) for i in range(6)]
+            torch.cuda.synchronize()
+            assert tr.graph_captured and (tr.buckets._comm is not None) == native
+            runs[native] = (losses, m.flat.P.clone(), m.flat.M.clone())
+            tr.buckets.close()
+        assert runs[False][0] == runs[True][0]
+        assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_failed_capture_falls_back_to_a_correct_eager_step(dev):
     """a capture that fails half-way (here: no page-locked plan table was left for the grouped weight-gradient
     launch, the failure DESIGN §6 records) leaves deferred launches behind that name tensors of work that never ran.
