@@ -1,5 +1,7 @@
 // Library-level entry points: version and thread-local error text.
 #include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <atomic>
 
@@ -12,6 +14,18 @@ void mrmt3_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int mrmt3_diag_env(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v != 0) {
+    static std::atomic<unsigned> warned{0};          // bit per switch name (two switches exist: hash by first letter after MRMT3_)
+    const unsigned bit = 1u << ((unsigned char)name[6] & 31);
+    if (!(warned.fetch_or(bit, std::memory_order_relaxed) & bit))
+      fprintf(stderr, "mrmt3: %s=%d is a kernel DIAGNOSTIC switch (parts of a kernel are knocked out): the results of this process are NOT valid\n", name, v);
+  }
+  return v;
 }
 
 extern "C" int mrmt3_version(void) { return 107; /* 0.1.7: round 4 (gemm_rows: projection + row kernel in one launch; 106: activation helpers as explicit FMAs; 107: mrmt3_comm_*, mrmt3_allreduce) */ }

@@ -19,6 +19,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // ---- error plumbing (never abort / throw across the C ABI) --------------------------------------
 void mrmt3_set_error(const char* fmt, ...);
 void mrmt3_count(int which);   // diagnostics: launches per kernel family (MRMT3_CNT_*), read by mrmt3_dispatch_counts
+// value of a DIAGNOSTIC environment switch whose non-zero settings knock parts of a kernel out (MRMT3_GEMM8_DBG,
+// MRMT3_ROWS_DBG): 0 when unset; a non-zero value is announced on stderr once per switch — results of such a process are wrong
+int mrmt3_diag_env(const char* name);
 #define MR_CHECK_ARG(cond, ...)                      \
   do {                                               \
     if (!(cond)) {                                   \

@@ -545,7 +545,7 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
   P.n_tiles = small ? ceil_div(M, 128) * P.tiles_n : tiles256;
   {
     // one tile ~ nk x 1.4 us (0.7 for 128-row tiles) + the stores; eight start phases across that period
-    { const char* e = getenv("MRMT3_GEMM8_DBG"); P.dbg = e ? atoi(e) : 0; }
+    P.dbg = mrmt3_diag_env("MRMT3_GEMM8_DBG");
     static int skew_pct = -1;
     if (skew_pct < 0) { const char* e = getenv("MRMT3_GEMM8_SKEW"); skew_pct = e ? atoi(e) : 0; }
     const double tile_us = (K / 64) * (small ? 0.7 : 1.4) + 1.5;
@@ -629,7 +629,7 @@ int mrmt3_gemm_nt8_splitk_try(const void* A, int lda, const void* B, int ldb, vo
   P.K = K / sp; P.kfull = K; P.ksplit = sp; P.mpad = mpad;
   P.tiles_n = ceil_div(N, 256);
   P.n_tiles = sp * (mpad / 128) * P.tiles_n;
-  { const char* e = getenv("MRMT3_GEMM8_DBG"); P.dbg = e ? atoi(e) : 0; }
+  P.dbg = mrmt3_diag_env("MRMT3_GEMM8_DBG");
   const int grid = (P.n_tiles + 7) & ~7;
   hipLaunchKernelGGL((gemm_nt8_kernel<float, false, 4>), dim3((unsigned)grid), dim3(512), 0, s, P);
   const size_t total = (size_t)M * (N >> 2);
@@ -684,7 +684,7 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
   auto fill = [&](int nt) { return (double)nt / ((double)ceil_div(nt, cus) * cus); };
   const bool small = tiles256 < cus || (tiles256 < 4 * cus && fill(tiles128) > fill(tiles256) + 0.15);
   P.n_tiles = small ? tiles128 : tiles256;
-  { const char* e = getenv("MRMT3_GEMM8_DBG"); P.dbg = e ? atoi(e) : 0; }
+  P.dbg = mrmt3_diag_env("MRMT3_GEMM8_DBG");
   P.skew_ticks = 0;
   int grid = P.n_tiles < cus ? ((P.n_tiles + 7) & ~7) : cus;
   if (small) hipLaunchKernelGGL((gemm_nt8_kernel<bf16_t, false, 4, 1>), dim3((unsigned)grid), dim3(512), 0, s, P);

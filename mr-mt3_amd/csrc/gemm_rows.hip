@@ -555,7 +555,7 @@ static unsigned gr_grid(int M, int n_ctiles, int bm) {
 static void gr_base(GRParams& P, const void* A, int lda, const void* W, int ldw, int M, int K, int n_ctiles) {
   memset(&P, 0, sizeof(P));
   P.A = (const bf16_t*)A; P.B = (const bf16_t*)W; P.lda = lda; P.ldb = ldw; P.M = M; P.K = K; P.n_ctiles = n_ctiles;
-  P.dbg = gr_env("MRMT3_ROWS_DBG", 0);
+  P.dbg = mrmt3_diag_env("MRMT3_ROWS_DBG");
   P.trace = g_rows_trace;
   P.skew_fine = gr_env("MRMT3_ROWS_SKEW_FINE", 0) / 10;
   if (P.dbg & 4) {
