@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, final tree: GPU suite + smoke, rocprofv3 kernel trace / stats of the bench command, whole-step PMC traffic, full bench
+# round 4, final tree (library 107): GPU suite + smoke, rocprofv3 kernel trace / stats of the bench command, whole-step PMC traffic, full bench
 mkdir -p gpurun_out/r4
 O=gpurun_out/r4
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
