@@ -41,7 +41,7 @@ class _CapturedStep:
 
 class Trainer:
     def __init__(self, model, lr: float = 2e-4, lr_lambda=None, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.01, weighted_loss: bool = False, layers_per_bucket: int = 2,
+                 weight_decay: float = 0.01, weighted_loss: bool = False, layers_per_bucket: int = 4,
                  graph: bool = None, grad_exchange_dtype=None):
         self.model, self.flat, self.engine = model, model.flat, model.engine
         assert model.device.type == "cuda", "the trainer drives the HIP kernels: move the model to the GPU first"
@@ -56,6 +56,12 @@ class Trainer:
         cfg = model.cfg
         if grad_exchange_dtype is None and os.environ.get("MRMT3_GRAD_EXCHANGE", "f32") == "bf16":
             grad_exchange_dtype = torch.bfloat16
+        # 4 layers per bucket = 4 buckets of 38-56 MB for MT3Net (5 with segment memory).  A bucket boundary costs 0.07 ms
+        # of step time (a graph segment of its own + the grouped weight-gradient launch split there: 16 / 8 / 4 / 2 buckets =
+        # 25.26 / 24.70 / 24.40 / 24.23 ms at one rank with forced collectives, plain step 24.17,
+        # profiles/r04_bucket_boundary_cost.txt); the LAST bucket's all-reduce is the one nothing overlaps, so fewer, larger
+        # buckets stop paying once that tail outgrows the boundaries saved (2 buckets: the whole encoder, 80 MB, at the end).
+        layers_per_bucket = max(1, int(os.environ.get("MRMT3_DDP_LAYERS_PER_BUCKET", layers_per_bucket)))
         self.buckets = GradBuckets(self.flat, cfg["num_layers"], cfg["num_decoder_layers"],
                                    model.segmem_num_layers > 0, layers_per_bucket, exchange_dtype=grad_exchange_dtype)
         self.buckets.before_fire = model.engine.join_wgrad      # norm-weight partials and split-K slabs are summed here
