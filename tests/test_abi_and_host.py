@@ -50,6 +50,24 @@ def test_device_code_has_no_packed_f32_instructions(tmp_path):
     assert n_mfma > 4000 and n_dma > 400, (n_mfma, n_dma)
 
 
+def test_comm_entry_points_resolve_rccl_without_linking_it():
+    """csrc/comm.hip finds RCCL with dlopen at first use (here: the copy torch has mapped); the library itself must not
+    carry a link-time dependency on it.  ncclGetUniqueId needs no device, so the id call works on this CPU box; argument
+    errors of the other entry points come back as codes with a message."""
+    import subprocess
+    so = lib.load()
+    needed = subprocess.run(["readelf", "-d", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "NEEDED" in needed and "rccl" not in needed.lower() and "nccl" not in needed.lower()
+    a, b = lib.Comm.unique_id(), lib.Comm.unique_id()
+    assert len(a) == len(b) == lib.COMM_ID_BYTES == 128 and a != b
+    assert so.mrmt3_comm_unique_id(None) != 0 and b"null" in so.mrmt3_last_error()
+    h = ctypes.c_void_p()
+    assert so.mrmt3_comm_create(ctypes.create_string_buffer(a, 128), 2, 2, ctypes.byref(h)) != 0     # rank out of range
+    assert b"rank 2 of 2" in so.mrmt3_last_error() and not h
+    assert so.mrmt3_comm_destroy(None) == 0
+    assert so.mrmt3_allreduce(None, None, 0, 0, 0, None) != 0
+
+
 def test_product_path_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lib.gemm_nt(torch.zeros(128, 64), torch.zeros(128, 64))
