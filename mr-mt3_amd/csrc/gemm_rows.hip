@@ -604,6 +604,8 @@ extern "C" int mrmt3_gemm_nt_normbwd(const void* A, int lda, const void* WT, int
   MR_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)WT % 16) == 0 && ((uintptr_t)dres % 16) == 0 && ((uintptr_t)x1 % 16) == 0 &&
                ((uintptr_t)dx1 % 16) == 0 && ((uintptr_t)dy_bf16 % 16) == 0 && ((uintptr_t)w_norm % 16) == 0,
                "gemm_nt_normbwd: operands must be 16-byte aligned");
+  MR_CHECK_ARG((dres_dtype == MRMT3_F32 || dres_dtype == MRMT3_BF16) && (dx1_dtype == MRMT3_F32 || dx1_dtype == MRMT3_BF16),
+               "gemm_nt_normbwd: unknown dtype code (dres %d, dx1 %d)", dres_dtype, dx1_dtype);
   const int n_part = mrmt3_gemm_nt_normbwd_partial_rows(rows);
   MR_CHECK_ARG(workspace == nullptr || workspace_bytes >= ((size_t)n_part + DW_CHUNKS) * 512 * sizeof(float) + 8 * sizeof(int),
                "gemm_nt_normbwd: workspace too small");
