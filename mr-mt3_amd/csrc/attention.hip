@@ -52,6 +52,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
   const int n_qt = ceil_div(P.Lq, 64 * RT);
   const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk), vres = rows_rsrc(vb, P.Lk, P.ldv);
   const unsigned k_lane = rows8_lane_off(P.ldk, lane), v_lane = rows8_lane_off(P.ldv, lane);
+  // 16-byte output rows need 16-byte aligned rows (kernel-uniform)
+  const bool wide_rows = (P.ldo & 7) == 0 && (((uintptr_t)P.out | (uintptr_t)P.o_lo_out) & 15) == 0;
 
   // causal: query tile t needs 2(t+1) key tiles, so a workgroup takes the PAIR (n_qt-1-t, t) — every workgroup
   // of the launch then does the same amount of work and the launch has no tail of heavy tiles
@@ -201,22 +203,46 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
     float l = l_run[qt];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (qrow[qt] >= P.Lq) continue;
+    const bool row_ok = qrow[qt] < P.Lq;
     const float inv = l > 0.f ? P.drop.scale / l : 0.f;    // the dropout keep scale is applied here, once
     const size_t ooff = ((size_t)b * P.Lq + qrow[qt]) * P.ldo + h * HD;
     bf16_t* orow = P.out + ooff;
+    u32x2 ch[4], cl[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 v = oT[qt][dt] * inv;
       const unsigned h01 = pack_bf2(v[0], v[1]), h23 = pack_bf2(v[2], v[3]);
-      *(u32x2*)(orow + dt * 16 + fg * 4) = u32x2{h01, h23};
+      ch[dt] = u32x2{h01, h23};
       if (P.o_lo_out) {
         const float r0 = v[0] - __uint_as_float(h01 << 16), r1 = v[1] - __uint_as_float(h01 & 0xFFFF0000u);
         const float r2 = v[2] - __uint_as_float(h23 << 16), r3 = v[3] - __uint_as_float(h23 & 0xFFFF0000u);
-        *(u32x2*)(P.o_lo_out + ooff + dt * 16 + fg * 4) = u32x2{pack_bf2(r0, r1), pack_bf2(r2, r3)};
+        cl[dt] = u32x2{pack_bf2(r0, r1), pack_bf2(r2, r3)};
+      } else {
+        cl[dt] = u32x2{0u, 0u};
       }
     }
-    if (fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] * LN2 + __logf(l);
+    if (wide_rows) {                        // 16-byte stores (see widen_rows); every lane of the wave takes part in the swaps
+      u32x4 w[2];
+      widen_rows(ch, w);
+      if (row_ok) {
+        *(u32x4*)(orow + widen_off(fg)) = w[0];
+        *(u32x4*)(orow + 32 + widen_off(fg)) = w[1];
+      }
+      if (P.o_lo_out) {
+        widen_rows(cl, w);
+        if (row_ok) {
+          *(u32x4*)(P.o_lo_out + ooff + widen_off(fg)) = w[0];
+          *(u32x4*)(P.o_lo_out + ooff + 32 + widen_off(fg)) = w[1];
+        }
+      }
+    } else if (row_ok) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *(u32x2*)(orow + dt * 16 + fg * 4) = ch[dt];
+        if (P.o_lo_out) *(u32x2*)(P.o_lo_out + ooff + dt * 16 + fg * 4) = cl[dt];
+      }
+    }
+    if (row_ok && fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] * LN2 + __logf(l);
   }
   }  // pass
 }

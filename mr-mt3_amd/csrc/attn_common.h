@@ -83,6 +83,20 @@ __device__ __forceinline__ float rows_max(float v) {
   r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
 }
+// Epilogue rows, widened (the guide's T21: per-lane 8-byte row stores are issue-bound, 16 quarter-lines per instruction).
+// A lane holds, of ONE output row, the four 8-byte chunks c[dt] = features 16 dt + 4 fg .. + 3 (the MFMA accumulator
+// layout with the row on the lane).  Two v_permlane16_swap per chunk pair trade chunks between the lane groups fg and
+// fg ^ 1, after which a lane owns 16 contiguous bytes twice: out[p] = features 32 p + widen_off(fg) .. + 7.  A store
+// instruction then writes 64 contiguous bytes per row instead of 32, and a row takes two instructions instead of four.
+__device__ __forceinline__ void widen_rows(const u32x2 c[4], u32x4 out[2]) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(c[2 * p].x, c[2 * p + 1].x, false, false);
+    const u32x2_t r1 = __builtin_amdgcn_permlane16_swap(c[2 * p].y, c[2 * p + 1].y, false, false);
+    out[p] = u32x4{r0.x, r1.x, r0.y, r1.y};
+  }
+}
+__device__ __forceinline__ int widen_off(int fg) { return (fg & 1) * 16 + (fg >> 1) * 8; }
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
