@@ -600,13 +600,19 @@ def _attn_executed_pairs(Lq, Lk, causal):
     return float(n)
 
 
-def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse=True, step=None, want_lo=None):
+def attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.0, seed=0, stream_id=0, want_lse=True, step=None, want_lo=None, out=None,
+             out_lo=None):
     """q: [B*Lq, ldq-view], k/v: [B*Lk, ld-view] 2-D views whose column 0 is head 0 / dim 0.
     want_lo (True / False instead of None): returns (o, lse, o_lo) with o_lo = bf16(O - bf16(O)) for the backward's
-    delta when True (and the kernel is the bf16 one), else None."""
+    delta when True (and the kernel is the bf16 one), else None.  out / out_lo: caller-owned [B*Lq, H*64] views of the same
+    row stride (a multiple of 4 elements; rows that are not 16-byte aligned take the kernel's 8-byte store path)."""
     _dev(q, k, v)
-    o = torch.empty(B * Lq, H * 64, device=q.device, dtype=q.dtype)
-    o_lo = torch.empty_like(o) if want_lo and q.dtype == torch.bfloat16 else None
+    o = torch.empty(B * Lq, H * 64, device=q.device, dtype=q.dtype) if out is None else out
+    assert o.shape == (B * Lq, H * 64) and o.dtype == q.dtype and o.stride(1) == 1
+    if out_lo is not None:
+        assert want_lo and out_lo.shape == o.shape and out_lo.stride(0) == o.stride(0) and out_lo.dtype == o.dtype
+    o_lo = (out_lo if out_lo is not None else torch.empty_like(o)) if want_lo and q.dtype == torch.bfloat16 else None
+    assert o_lo is None or o_lo.stride(0) == o.stride(0)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
     # algorithmic FLOPs count the full (unskipped) square, as the reference computes it (SURVEY §8d)
     with _Timed("attn_fwd", 4.0 * B * H * Lq * Lk * 64, "FLOP", executed=4.0 * B * H * 64 * _attn_executed_pairs(Lq, Lk, causal)):

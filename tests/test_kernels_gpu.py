@@ -1247,3 +1247,25 @@ def test_grouped_weight_gradients_match_f32_and_are_bitwise_repeatable(dev, monk
                               torch.zeros(512, 512, device=dev))         # too few rows: goes through mrmt3_gemm_tn
     assert not lib.TnGroup.ok(torch.zeros(4096, 320, device=dev).bfloat16(), torch.zeros(4096, 512, device=dev).bfloat16(),
                               torch.zeros(320, 512, device=dev))
+
+
+@pytest.mark.parametrize("causal,Lq,Lk", [(True, 256, 256), (False, 200, 256), (False, 128, 320)])
+def test_attn_fwd_row_store_paths_agree(dev, causal, Lq, Lk):
+    """The forward kernel writes its output rows 16 bytes per lane (two v_permlane16_swap per chunk pair) when the rows are
+    16-byte aligned, 8 bytes per lane otherwise: same bits either way, for O, its low half and the log-sum-exp, with a ragged
+    last query tile and with dropout."""
+    from mrmt3 import lib
+    B, H = 3, 6
+    torch.manual_seed(5)
+    qkv = torch.randn(B * max(Lq, Lk), 1152, device=dev).bfloat16()
+    q, k, v = qkv[:B * Lq, :384], qkv[:B * Lk, 384:768], qkv[:B * Lk, 768:]
+    o, lse, o_lo = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.1, seed=9, stream_id=2, want_lo=True)
+    for ld, col0 in ((388, 0), (392, 4)):           # rows 8 bytes off / aligned stride but an 8-byte offset base
+        buf = torch.full((B * Lq, ld), 7.0, device=dev).bfloat16()
+        buf_lo = torch.full((B * Lq, ld), 7.0, device=dev).bfloat16()
+        o2, lse2, lo2 = lib.attn_fwd(q, k, v, B, H, Lq, Lk, causal, p=0.1, seed=9, stream_id=2, want_lo=True,
+                                     out=buf[:, col0:col0 + 384], out_lo=buf_lo[:, col0:col0 + 384])
+        assert torch.equal(o2, o) and torch.equal(lo2, o_lo) and torch.equal(lse2, lse)
+        pad = torch.ones(ld, dtype=torch.bool, device=dev)
+        pad[col0:col0 + 384] = False
+        assert (buf[:, pad] == 7.0).all() and (buf_lo[:, pad] == 7.0).all()      # nothing written outside the rows
