@@ -11,6 +11,12 @@ Workload at N=1 = BASELINE.json configs[1]: MT3Net (T5-small) bf16, batch 64 seg
 (32768 samples @16 kHz -> 256 mel frames), 1024-token targets, golden-recipe weights.
 Data parallel: every rank draws its own 64 segments (weak scaling); value = N*64*K / max-rank time.
 
+`--gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment) starts the N ranks itself: this process —
+which has not touched the GPU — runs `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a
+CHILD process, forwards rank 0's JSON line and exits with the child's code (the reference gets its ranks from its launcher
+the same way: config/config.yaml:45-46 `devices`, train.sh:6).  More ranks than visible GPUs is refused, and so is a
+launcher whose WORLD_SIZE differs from --gpus: the line never reports fewer GPUs than were asked for.
+
 Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel family, measured with
 events on the launch stream in an instrumented pass of the same steps), `cpu_baseline` (the CPU
 oracle timed on this host, N=1 only) and `inference` (greedy decode RTF, hipGraph replayed steps).
@@ -33,10 +39,12 @@ import torch.distributed as dist
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_SEG_FWD_BWD = 225.1e9   # MT3Net, SURVEY §8d (full causal square counted, as the reference computes it)
+FLOP_PER_SEG_MRMT3 = 248.0e9     # segmem_v2_with_prev, 64 memory slots, as written
+FLOP_PER_SEG_LONG = 707.5e9      # the same model on 2048-frame segments (BASELINE configs[4])
 SEG_SECONDS = 32768 / 16000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -50,7 +58,47 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--extra-batch", type=int, default=12, help="also time this per-GPU batch (0 = off)")
-    return ap.parse_args()
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip train_mrmt3 / train_mrmt3_b12 / train_long_context (BASELINE configs[2] and [4])")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (the N > 1 code path on one GPU)")
+    return ap.parse_args(argv)
+
+
+def visible_gpus():
+    """Devices this process could use, WITHOUT initialising the GPU (device_count() only reads the driver's list): the
+    parent of the ranks must stay off the GPU."""
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(args, argv, launcher=None, n_visible=None, out_fd=1):
+    """`bench.py --gpus N` without a launcher around it: run the N ranks as a child `torch.distributed.run`, forward
+    rank 0's JSON line to `out_fd`, return the child's exit code.  `launcher` (tests) replaces the command prefix."""
+    import socket
+    import subprocess
+    n_visible = visible_gpus() if n_visible is None else n_visible
+    if args.gpus > n_visible:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible: refusing to run fewer ranks than asked for\n"
+                         % (args.gpus, n_visible))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child_args = [a for a in argv if a != "--spawn"]
+    cmd = (list(launcher) if launcher is not None else
+           [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port)]) + [os.path.abspath(__file__)] + child_args
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+    env["MRMT3_BENCH_SPAWNED"] = "1"
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        os.write(out_fd, (lines[-1] + "\n").encode())
+    elif r.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+        return 3
+    return r.returncode
 
 
 def build_model(variant, dev, dtype=torch.bfloat16):
@@ -88,6 +136,46 @@ def roofline_pass(trainer, audio, labels, prev, steps):
         f["n"] += 1
     lib.PROFILE = None
     return fam
+
+
+def timed_workload(dev, variant, B, n_samples, steps, flop_per_seg, lr=2e-4, lr_lambda=None, seed=365):
+    """One more training workload beside the headline one, same step (log-mel + fwd + CE + bwd + AdamW, dropout on, graph
+    replays): ms per step, segments/s, model TFLOP/s and the three kernel families that take most of the step (events
+    around every launch of an eager repeat, as roofline_pass does).  A model and trainer of its own, released at the end."""
+    from mrmt3.synthetic import synth_audio, synth_labels
+    from mrmt3.trainer import Trainer
+    model = build_model(variant, dev)
+    tr = Trainer(model, lr=lr, lr_lambda=lr_lambda)
+    audio = torch.from_numpy(synth_audio(B, n_samples, seed=seed)).to(dev)
+    labels = torch.from_numpy(synth_labels(B, seed=seed)).to(dev)
+    prev = torch.from_numpy(synth_labels(B, seed=1000 + seed)).to(dev) if variant == "segmem_v2_with_prev" else None
+    step = lambda: tr.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
+    while tr.use_graph and not tr.graph_captured:
+        step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"variant": variant, "segments_per_gpu": B, "mel_frames": -(-n_samples // 128), "ms_per_step": 1e3 * dt,
+           "segments_per_s": B / dt, "audio_seconds_per_step": B * n_samples / 16000.0,
+           "model_tflops": B / dt * flop_per_seg / 1e12, "model_flop_per_segment": flop_per_seg,
+           "step_graph": bool(tr.use_graph and tr.graph_captured), "final_loss": float(loss.item()),
+           "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
+    graph_was, tr.use_graph = tr.use_graph, False
+    was, tr.engine.overlap_wgrad = tr.engine.overlap_wgrad, False
+    n_rf = 2
+    fam = roofline_pass(tr, audio, labels, None if prev is None else prev.clone(), n_rf)
+    tr.engine.overlap_wgrad, tr.use_graph = was, graph_was
+    ms = {k: v["ms"] / n_rf for k, v in fam.items() if "@" not in k}
+    out["eager_timed_ms_per_step"] = sum(ms.values())
+    out["top3_families_ms_per_step"] = dict(sorted(ms.items(), key=lambda kv: -kv[1])[:3])
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(seconds):
@@ -297,7 +385,14 @@ def pmc_table(batch, lib_version):
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(launch_ranks(args, argv))                 # (nothing above has touched the GPU)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d under a launcher with WORLD_SIZE=%s: they must agree\n"
+                         % (args.gpus, os.environ.get("WORLD_SIZE")))
+        sys.exit(2)
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 while the bench
     # runs (RCCL prints a five-line version banner there when its first communicator is created) goes to stderr
     sys.stdout.flush()
@@ -312,6 +407,8 @@ def main():
     force_coll = os.environ.get("MRMT3_DDP_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ
     if world > 1 or force_coll:    # (force: the RCCL bucket path at world size 1, for the record in profiles/)
         dist.init_process_group("nccl", device_id=dev)
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1      # what RCCL's communicator says, not the flag
+    assert ranks_seen == world, (ranks_seen, world)
     from mrmt3 import lib
     lib.load()
     from mrmt3.synthetic import synth_audio, synth_labels
@@ -352,7 +449,10 @@ def main():
 
     res = {
         "metric": "train segments/sec (T5-small MT3Net, 256-frame mel, 1024-token target; log-mel + fwd + bwd + AdamW)",
-        "value": seg_per_s, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": seg_per_s, "unit": "segments/s", "n_gpus": world, "ranks_seen": ranks_seen,
+        "launched_by": ("bench.py --gpus %d -> child torch.distributed.run" % args.gpus if os.environ.get("MRMT3_BENCH_SPAWNED")
+                        else "external launcher (WORLD_SIZE=%d)" % world if "WORLD_SIZE" in os.environ else "single process"),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %s bf16, %d segments/GPU/step of 32768 samples @16kHz -> 256x512 mel, "
@@ -448,6 +548,16 @@ def main():
             res["roofline"]["step"].update({"step_bytes": None, "hbm_GBps": None, "hbm_frac": None, "source": tab_note})
         if traffic is None:
             res["roofline"]["traffic_note"] = tab_note
+    if rank == 0 and world == 1 and not args.no_extra_workloads:
+        # MR-MT3's own model (BASELINE configs[2]: config_slakh_segmem.yaml, segment memory from the previous segment's
+        # tokens, models/t5_segmem_v2_with_prev.py:118-128) at the benchmark's 64 segments per GPU and at the reference's
+        # 12 (num_rows_per_batch), and configs[4]: the finetune config (bare AdamW, lr 1e-5) on 2048-frame segments + 64
+        # memory slots, 12 segments of 16.4 s per GPU.  Each is the same timed step as the headline line.
+        lam = cosine_warmup_lambda(64500, 1289 * 800, min_lr=1e-4)
+        res["train_mrmt3"] = timed_workload(dev, "segmem_v2_with_prev", B, 32768, args.steps, FLOP_PER_SEG_MRMT3, lr_lambda=lam)
+        res["train_mrmt3_b12"] = timed_workload(dev, "segmem_v2_with_prev", 12, 32768, args.steps, FLOP_PER_SEG_MRMT3, lr_lambda=lam)
+        res["train_long_context"] = timed_workload(dev, "segmem_v2_with_prev", 12, 2048 * 128, args.steps, FLOP_PER_SEG_LONG,
+                                                   lr=1e-5)
     sync()
     if rank == 0 and not args.no_inference:
         del trainer, model

@@ -73,13 +73,28 @@ void mrmt3_host_free(void* p);
 #define MRMT3_CNT_N 15
 int mrmt3_dispatch_counts(unsigned long long* out, int n, int reset);
 
+/* Dispatch / tuning switches ("knobs").  Which kernel or tile shape a call takes is a function of its arguments; a few
+ * MRMT3_* environment variables override that choice for A/B measurements and for the parity tests that hold two
+ * implementations against each other (MRMT3_ROWS_BM, MRMT3_GEMM8, MRMT3_TN8, MRMT3_LOGMEL, MRMT3_ATTN_ONEPASS, ...; the
+ * sources name each one where it is read).  The library reads a knob from the environment ONCE per process, at the first
+ * launch that asks for it; later changes of the environment are not seen and no launch path calls getenv again.
+ * mrmt3_set_knob(name, value) overrides a knob in-process from the next launch on (name = the variable's name, value = the
+ * integer the variable would hold); mrmt3_reset_knobs() drops every override and re-reads the environment at the next use.
+ * Process-wide, for tests and tuning: not to be changed while another thread launches. */
+int mrmt3_set_knob(const char* name, int value);
+int mrmt3_reset_knobs(void);
+
 /* ---- K1: log-mel frontend ---------------------------------------------------------------------
  * contrib/spectrograms.py:92-103,128-145 (pad_end, MelSpectrogram(n_fft 2048, hop, power 1,
  * center False), safe_log) + dataset/dataset_2_random.py:288-289 (clip/scale when normalize!=0)
  * + inference.py:125-126 (frames >= valid_frames[b] are zeroed; valid_frames may be NULL).
  * audio [batch][n_samples] f32 -> out [batch][ceil(n_samples/hop)][n_mels] f32 (or bf16).
  * window [2048] f32; twiddle [1024][2] f32 = exp(-2*pi*i*k/2048); the filterbank is passed in
- * compressed rows: filter m = sum_{q<fb_cnt[m]} fb_w[m*max_taps+q] * |X[fb_start[m]+q]|. */
+ * compressed rows: filter m = sum_{q<fb_cnt[m]} fb_w[m*max_taps+q] * |X[fb_start[m]+q]|, fb_w [n_mels][max_taps];
+ * what fb_w holds at taps q >= fb_cnt[m] is never used (no zero padding required), 0 <= fb_start[m] <= 1024.
+ * Two kernels compute this: the wave-per-frame kernel (n_mels = 512, max_taps <= 12, even hop, fb_start 16-byte and
+ * window 8-byte aligned, out 16-byte aligned — the model's configuration) and the general one for everything else;
+ * the choice is by these arguments alone and both honour the contract above. */
 int mrmt3_logmel_fwd(const float* audio, int batch, int n_samples, int hop, const float* window,
                      const float* twiddle, const int* fb_start, const int* fb_cnt, const float* fb_w,
                      int n_mels, int max_taps, const int* valid_frames, int normalize, int out_bf16,
@@ -272,13 +287,13 @@ int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int ldw, void* h
  * mrmt3_gemm_nt_normbwd = mrmt3_gemm_nt (dxn = A . WT^T, [rows][512] bf16) + mrmt3_add_rmsnorm_bwd(dxn, dres, ...) with
  *   out_drop = 0: dx1 (f32 or bf16, may be dres itself), dy_bf16 (masked by stream_y, nullable) and — when `workspace`
  *   is given (mrmt3_add_rmsnorm_bwd_workspace_bytes(rows, 512) bytes suffice) — the norm-weight gradient's partial rows,
- *   mrmt3_gemm_nt_normbwd_partial_rows(rows) of them (one per 64 rows), left for mrmt3_norm_dw_reduce.
+ *   mrmt3_gemm_nt_normbwd_partial_rows(rows) of them (one per tile of rows), left for mrmt3_norm_dw_reduce.
+ * Tile height: 64 rows (two workgroups per CU) until ceil(rows / 128) reaches the CU count, 128 rows (one workgroup per
+ * CU, half the weight bytes staged per row) from there on — a function of `rows` alone, so the partial-row count is too.
+ * The knob MRMT3_ROWS_BM = 64 / 128 forces one height (parity tests run every case under both).
  * mrmt3_gemm_nt_geglubwd = mrmt3_gemm_nt (dg = dy . WT^T, [rows][dff] bf16, WT = wo^T [dff][K]) + mrmt3_geglu_bwd(h, dg):
  *   dh [rows][2 dff] bf16.  Same bits as the two kernels. */
 int mrmt3_gemm_rows_ok(int M, int N, int K, int lda, int ldw);
-/* diagnostics: while `buf` (device, [workgroups][8] uint64) is set, every fused launch leaves its workgroups' phase
- * timestamps there (10-ns ticks: start, K loop start, K loop end, tile image written, end); NULL switches it off */
-int mrmt3_gemm_rows_trace(void* buf);
 int mrmt3_gemm_nt_addnorm(const void* A, int lda, const void* W, int ldw, int rows, int K, const float* x0,
                           const float* w_norm, float eps, float* x1, void* xn_bf16, float* rstd, float p_drop,
                           uint64_t seed, const int32_t* step_dev, uint32_t stream_y, uint32_t stream_out, int out_drop,
@@ -430,6 +445,18 @@ int mrmt3_comm_unique_id(void* id_out);
 int mrmt3_comm_create(const void* id, int rank, int world, void** comm_out);
 int mrmt3_comm_destroy(void* comm);
 int mrmt3_allreduce(void* comm, void* buf, size_t count, int dtype, int average, void* stream);
+
+/* Counting hand-offs between two streams whose work is replayed as two separate hipGraphs (the data-parallel step with its
+ * all-reduces captured: one graph of compute, one of collectives, mrmt3/trainer.py).  flag / seen / err: int32 in device
+ * memory, zero before first use.
+ *   mrmt3_flag_signal : *flag += 1 once everything enqueued before it on `stream` has completed (release, device scope).
+ *   mrmt3_flag_wait   : `stream` proceeds once *flag >= *seen + 1, then *seen += 1 (only waits on this stream touch seen).
+ *                       After timeout_ms without the signal it sets *err = 1 and lets the stream go on: a step whose other
+ *                       graph never ran ends in an error word for the host to read, not in a GPU that spins for ever.
+ * Both capture into a graph as ordinary kernel nodes; unlike an event-wait node, a wait cannot be satisfied by the previous
+ * replay's signal. */
+int mrmt3_flag_signal(int32_t* flag, void* stream);
+int mrmt3_flag_wait(const int32_t* flag, int32_t* seen, int32_t* err, int timeout_ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "common.h"
 
@@ -16,6 +17,7 @@ void mrmt3_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+#ifdef MRMT3_DIAG
 int mrmt3_diag_env(const char* name) {
   const char* e = getenv(name);
   const int v = e ? atoi(e) : 0;
@@ -27,8 +29,76 @@ int mrmt3_diag_env(const char* name) {
   }
   return v;
 }
+#endif
 
-extern "C" int mrmt3_version(void) { return 107; /* 0.1.7: round 4 (gemm_rows: projection + row kernel in one launch; 106: activation helpers as explicit FMAs; 107: mrmt3_comm_*, mrmt3_allreduce) */ }
+// ---- knobs (common.h): environment switches read once per process, overridable through the ABI ------------------------
+namespace {
+std::mutex g_knob_mu;
+MrKnob* g_knob_sites = nullptr;                     // every MR_KNOB site that has been read
+struct KnobOverride { char name[48]; int value; };
+KnobOverride g_knob_over[32];
+int g_knob_n_over = 0;
+
+bool knob_parse(const char* e, int* out) {
+  if (e == nullptr || *e == 0) return false;
+  char* end = nullptr;
+  const long v = strtol(e, &end, (e[0] == '0' && (e[1] == 'x' || e[1] == 'X')) ? 16 : 10);
+  if (end == e) return false;
+  *out = (int)v;
+  return true;
+}
+// (lock held) the value the process should see for `name`: an override, else the environment, else `dflt`
+int knob_resolve(const char* name, int dflt) {
+  for (int i = 0; i < g_knob_n_over; ++i)
+    if (strcmp(g_knob_over[i].name, name) == 0) return g_knob_over[i].value;
+  int v;
+  return knob_parse(getenv(name), &v) ? v : dflt;
+}
+}  // namespace
+
+int mrmt3_knob_get(MrKnob* k, int dflt) {
+#ifndef MRMT3_DIAG
+  if (k->state == 1) return k->value;               // the launch path after the first use: one load, no environment access
+#endif
+  std::lock_guard<std::mutex> lock(g_knob_mu);
+  const int v = knob_resolve(k->name, dflt);
+#ifndef MRMT3_DIAG
+  if (!k->registered) { k->registered = 1; k->next = g_knob_sites; g_knob_sites = k; }
+  k->value = v;
+  k->state = 1;
+#endif
+  return v;
+}
+
+extern "C" int mrmt3_set_knob(const char* name, int value) {
+  if (name == nullptr || strncmp(name, "MRMT3_", 6) != 0 || strlen(name) >= sizeof(g_knob_over[0].name)) {
+    mrmt3_set_error("set_knob: a knob is named MRMT3_<SWITCH> (at most %zu characters)", sizeof(g_knob_over[0].name) - 1);
+    return MRMT3_ERR_INVALID_ARG;
+  }
+  std::lock_guard<std::mutex> lock(g_knob_mu);
+  int i = 0;
+  while (i < g_knob_n_over && strcmp(g_knob_over[i].name, name) != 0) ++i;
+  if (i == g_knob_n_over) {
+    if (g_knob_n_over == (int)(sizeof(g_knob_over) / sizeof(g_knob_over[0]))) {
+      mrmt3_set_error("set_knob: more than %d overrides", g_knob_n_over);
+      return MRMT3_ERR_INVALID_ARG;
+    }
+    strcpy(g_knob_over[g_knob_n_over++].name, name);
+  }
+  g_knob_over[i].value = value;
+  for (MrKnob* k = g_knob_sites; k != nullptr; k = k->next)
+    if (strcmp(k->name, name) == 0) k->state = 0;   // re-resolved (to the override) at the next launch that asks
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_reset_knobs(void) {
+  std::lock_guard<std::mutex> lock(g_knob_mu);
+  g_knob_n_over = 0;
+  for (MrKnob* k = g_knob_sites; k != nullptr; k = k->next) k->state = 0;   // back to the environment's value (or the default)
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_version(void) { return 108; /* 0.1.8: round 5 (knobs read once per process + mrmt3_set_knob; kernel diagnostics only in the -DMRMT3_DIAG build); 107: round 4 */ }
 extern "C" const char* mrmt3_last_error(void) { return g_err; }
 
 // Page-locked host memory for tables the device reads through an async copy (the grouped weight-gradient plan): owned by

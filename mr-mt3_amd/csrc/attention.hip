@@ -32,10 +32,7 @@
 #define KV_STAGES 3
 #define KV_STAGE_BYTES 16384   // K tile 8 KiB + V tile 8 KiB
 
-static int attn_tile_mode() {
-  const char* e = getenv("MRMT3_ATTN_TILE_MODE");      // tuning only
-  return e ? (int)strtol(e, nullptr, 0) : 5;
-}
+static int attn_tile_mode() { return MR_KNOB("MRMT3_ATTN_TILE_MODE", 5); }      // tuning only
 
 template <bool PAIR, bool DROP, int RT = 2>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {

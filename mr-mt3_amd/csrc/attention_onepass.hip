@@ -244,10 +244,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnParams P) 
 // below that the two-pass kernels' 128-row tiles fill the chip better.
 int mrmt3_attn_bwd_onepass_try(const AttnParams& P, hipStream_t s) {
   int min_bh = 96;
-  const char* e = getenv("MRMT3_ATTN_ONEPASS");              // A/B switch, read per call (tuning / tests only)
-  const bool enabled = !(e && e[0] == '0');
-  const char* m = getenv("MRMT3_ATTN_ONEPASS_MIN_BH");
-  if (m && atoi(m) > 0) min_bh = atoi(m);
+  const bool enabled = MR_KNOB("MRMT3_ATTN_ONEPASS", 1) != 0;     // A/B switch (tuning / tests only)
+  const int m = MR_KNOB("MRMT3_ATTN_ONEPASS_MIN_BH", 0);
+  if (m > 0) min_bh = m;
   if (!enabled || P.causal || P.Lk != OP_LK || P.B * P.H < min_bh || P.Lq < 32) return 0;
   const dim3 grid((unsigned)P.H, (unsigned)P.B);
   if (P.drop.thresh8) hipLaunchKernelGGL((attn_bwd_onepass_kernel<true>), grid, dim3(512), 0, s, P);

@@ -170,8 +170,8 @@ static inline bool attn_paired(int L, int causal, int H, int B) {
 // (16 rows per wave, RT = 1 instantiations) instead, twice the workgroups.  MRMT3_ATTN_FINE=0 / 1 forces it (tuning).
 static inline bool attn_fine(int L, bool paired, int causal, int H, int B) {
   if (paired || L <= 64) return false;
-  const char* e = getenv("MRMT3_ATTN_FINE");                // (read per call: tests switch it)
-  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  const int e = MR_KNOB("MRMT3_ATTN_FINE", -1);             // (tests switch it: mrmt3_set_knob)
+  if (e == 0 || e == 1) return e == 1;
   // causal launches that are too small to pair (up to 21 segments) have unequal tiles: the finer grain balances them
   // (20 segments: forward 54.8 -> 50.0 us, backward 148.4 -> 131.2 us); equal tiles only while the chip is underfilled
   // (cross-attention forward at 16-32 segments is 7-10 % slower with 64-row tiles)

@@ -122,3 +122,46 @@ extern "C" int mrmt3_allreduce(void* comm, void* buf, size_t count, int dtype, i
                                  c->nccl, (hipStream_t)stream), "allreduce");
   return MRMT3_OK;
 }
+
+// ---- hand-offs between two replayed graphs --------------------------------------------------------------------------------
+// The data-parallel step as TWO hipGraphs on two streams (mrmt3/trainer.py, MRMT3_DDP_GRAPH=1): the compute chain and the
+// chain of the gradient buckets' all-reduces.  Each is captured as ONE linear chain (ROCm 7.2 maps forked graphs badly: a
+// graph with a side branch replayed in 40.9 instead of 25 ms), and what one graph has to tell the other —
+// "bucket i is complete", "every bucket is reduced" — goes through counting flags in device memory instead of events:
+// an event-wait node waits for whatever record is the latest when it RUNS, which for two graphs replayed side by side may
+// be the previous step's (already complete) one; a counter cannot be satisfied by an old signal.
+//   signal: flag += 1 (release, agent scope), after everything before it on its stream
+//   wait:   until flag >= seen + 1 (acquire, agent scope), then seen += 1.  `seen` belongs to the waiting side alone.
+// A wait gives up after `timeout_ms` (the other graph was never launched, or failed): it raises *err and lets its stream go
+// on, so that a broken step shows up as an error word the host checks — never as a GPU that spins for ever.
+__global__ void flag_signal_kernel(int* flag) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(const int* flag, int* seen, int* err, unsigned long long timeout_ticks) {
+  if (threadIdx.x != 0) return;
+  const int want = *seen + 1;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();                  // 100 MHz
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+    __builtin_amdgcn_s_sleep(64);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  *seen = want;
+}
+
+extern "C" int mrmt3_flag_signal(int32_t* flag, void* stream) {
+  MR_CHECK_ARG(flag, "flag_signal: null pointer");
+  hipLaunchKernelGGL(flag_signal_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)flag);
+  MR_CHECK_LAUNCH("flag_signal");
+  return MRMT3_OK;
+}
+
+extern "C" int mrmt3_flag_wait(const int32_t* flag, int32_t* seen, int32_t* err, int timeout_ms, void* stream) {
+  MR_CHECK_ARG(flag && seen && err && timeout_ms > 0, "flag_wait: null pointer or no timeout");
+  hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)flag, (int*)seen, (int*)err,
+                     (unsigned long long)timeout_ms * 100000ull);
+  MR_CHECK_LAUNCH("flag_wait");
+  return MRMT3_OK;
+}

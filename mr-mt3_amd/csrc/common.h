@@ -19,9 +19,31 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // ---- error plumbing (never abort / throw across the C ABI) --------------------------------------
 void mrmt3_set_error(const char* fmt, ...);
 void mrmt3_count(int which);   // diagnostics: launches per kernel family (MRMT3_CNT_*), read by mrmt3_dispatch_counts
-// value of a DIAGNOSTIC environment switch whose non-zero settings knock parts of a kernel out (MRMT3_GEMM8_DBG,
-// MRMT3_ROWS_DBG): 0 when unset; a non-zero value is announced on stderr once per switch — results of such a process are wrong
+// ---- dispatch / tuning switches ("knobs") -------------------------------------------------------------------------------
+// A knob is an environment variable (MRMT3_*) that picks between kernels or tile shapes for A/B runs and parity tests.  The
+// product build reads each one ONCE per process — at the first launch that asks — and never touches the environment on a
+// launch path again; mrmt3_set_knob() / mrmt3_reset_knobs() (include/mrmt3_hip.h) override them in-process (tests, tuning).
+// MR_KNOB(name, default) is the cached value at its call site.  The -DMRMT3_DIAG build (libmrmt3_hip_diag.so, loaded by
+// profiles/tools through MRMT3_TOOL_LIB) re-reads the environment on every call so that one process can A/B a switch.
+struct MrKnob {
+  const char* name;
+  int state;      // 0 not read yet, 1 value cached
+  int value;
+  int registered;
+  MrKnob* next;   // registry (api.hip): every site that has been read, so that an override reaches it
+};
+int mrmt3_knob_get(MrKnob* k, int dflt);
+#define MR_KNOB(NAME, DFLT) ([]() -> int { static MrKnob k_ = {NAME, 0, 0, 0, nullptr}; return mrmt3_knob_get(&k_, (DFLT)); }())
+
+// Kernel DIAGNOSTICS (knock-outs of loads / MFMAs / stores, start skews, per-workgroup time stamps: the experiments DESIGN §0d
+// lists as measured and closed) exist only in the -DMRMT3_DIAG build; in the product MR_DIAG(x) is the constant 0 and the
+// branches fold away.  mrmt3_diag_env: value of such a switch, announced on stderr once (results of that process are wrong).
+#ifdef MRMT3_DIAG
+#define MR_DIAG(expr) (expr)
 int mrmt3_diag_env(const char* name);
+#else
+#define MR_DIAG(expr) 0
+#endif
 #define MR_CHECK_ARG(cond, ...)                      \
   do {                                               \
     if (!(cond)) {                                   \

@@ -243,10 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void gemm_nt_kernel(const TIN* __r
 // gemm8.hip: the ping-pong kernel for the tall bf16 shapes (returns 0 when the shape is not its)
 int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        int out_dtype, int accumulate, hipStream_t s);
-static bool use_gemm8() {
-  const char* e = getenv("MRMT3_GEMM8");        // tuning / A-B switch only (read per call: in-process A/B runs)
-  return !(e && e[0] == '0');
-}
+static bool use_gemm8() { return MR_KNOB("MRMT3_GEMM8", 1) != 0; }        // tuning / A-B switch only
 
 template <typename TIN, typename TOUT, bool ACCUM>
 static int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -531,8 +528,7 @@ int mrmt3_tn8_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per
 int mrmt3_tn8_launch(const void* A, int lda, const void* B, int ldb, float* slab, int M, int N1, int N2, int tiles,
                      int splits, int rps, hipStream_t s);
 static bool use_tn8(int M, int N1, int N2, int* tiles, int* splits, int* rps) {
-  const char* e = getenv("MRMT3_TN8");              // tuning / A-B switch only
-  if (e && e[0] == '0') return false;
+  if (MR_KNOB("MRMT3_TN8", 1) == 0) return false;   // tuning / A-B switch only
   return mrmt3_tn8_plan(M, N1, N2, tiles, splits, rps) != 0;
 }
 

@@ -39,6 +39,8 @@
 #include "common.h"
 
 #define G8_OOB 0x7FFF0000
+// kernel knock-outs (MRMT3_GEMM8_DBG) and the start skew exist in the diagnostics build only (common.h: MR_DIAG)
+#define G8_DBG(bit) MR_DIAG(P.dbg & (bit))
 #define G8_HALF 16384
 #define G8_BUF (4 * G8_HALF)
 
@@ -66,10 +68,7 @@ struct G8Params {
 // C store mode (G8Params::nt_c), MRMT3_GEMM8_NT: bit 0 streaming C, bit 1 streaming g (fused wi + GEGLU launch).
 // Default 2: plain C stores.  Same-box, three alternations at 64 segments: 3 (both streaming, the round-2 state) 25.80 ms,
 // 1 25.77, 2 25.61, 0 25.63 — the consumer of C is the next kernel and finds it in the Infinity Cache.
-static int g8_store_mode() {
-  const char* e = getenv("MRMT3_GEMM8_NT");
-  return e ? atoi(e) & 3 : 2;
-}
+static int g8_store_mode() { return MR_KNOB("MRMT3_GEMM8_NT", 2) & 3; }
 
 static int g8_cus() {
   static int n = 0;
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   // together: 32 MB of C leave the chip in one burst at the HBM write rate (measured: 6.2 us per tile with the MFMA
   // pipes idle, against 11 us for the tile's K loop at K = 512), then HBM idles through the next K loop.  Spread over
   // a tile period the same bytes need less than half the write bandwidth and drain behind the next tile's MFMAs.
-  if (P.skew_ticks > 0 && (slot & 7)) {
+  if (MR_DIAG(P.skew_ticks > 0) && (slot & 7)) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long wait = (unsigned long long)(slot & 7) * P.skew_ticks;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
@@ -202,14 +201,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   const int piece0 = w * 1024;                              // LDS offset of this wave's piece inside a half-tile
 
   auto load_a = [&](int buf, int half, int soff) {          // half 0: HA0, 1: HA1
-    if (P.dbg & 16) soff = G8_OOB;
+    if (G8_DBG(16)) soff = G8_OOB;
     unsigned char* base = lds + buf * G8_BUF + half * G8_HALF + piece0;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       g8_dma16(ra, base + i * 8192, voffA[i] + (half ? a1_delta : 0u), soff);
   };
   auto load_b = [&](int buf, int half, int soff) {          // half 0: HB0, 1: HB1
-    if (P.dbg & 16) soff = G8_OOB;
+    if (G8_DBG(16)) soff = G8_OOB;
     unsigned char* base = lds + buf * G8_BUF + (2 + half) * G8_HALF + piece0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   }
   auto cursor_next = [&]() {
     ++l_k;
-    if (l_k < nk) { if (!(P.dbg & 4)) { l_sa += 128; l_sb += 128; } return; }
+    if (l_k < nk) { if (!(G8_DBG(4))) { l_sa += 128; l_sb += 128; } return; }
     l_k = 0;
     ++l_it;
     if (l_it < my_tiles) {
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto read_a = [&](int buf, int half) {
-    if (P.dbg & 8) return;
+    if (G8_DBG(8)) return;
     const unsigned char* p = lds + buf * G8_BUF + half * G8_HALF;
 #pragma unroll
     for (int i = 0; i < RH; ++i) {
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
     }
   };
   auto read_b = [&](int buf, int half) {
-    if (P.dbg & 8) return;
+    if (G8_DBG(8)) return;
     const unsigned char* p = lds + buf * G8_BUF + half * G8_HALF;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   // Stores share the in-order vmcnt queue with the loads: the counted waits of these K steps allow for the batches
   // that are younger than the load they wait for.
   auto store_rows = [&](int i0, int m0, int n0, int cmin, bool count) __attribute__((always_inline)) {
-    if (P.dbg & 1) return;
+    if (G8_DBG(1)) return;
     if constexpr (EPI == 1) {
       // gated GELU: three 16-byte stores per row tile (h0, h1, g), rows on fr, 8 features per lane
       const int f0 = n0 + wc * 32 + fg * 8;
@@ -338,13 +337,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
         }
         if (row < P.M) {
           bf16_t* hp = (bf16_t*)P.C + (size_t)row * P.ldc + f0;
-          if (!(P.dbg & 64)) {
+          if (!(G8_DBG(64))) {
             __builtin_nontemporal_store((u32x4{h0p[0], h0p[1], h0p[2], h0p[3]}), (u32x4*)hp);
             __builtin_nontemporal_store((u32x4{h1p[0], h1p[1], h1p[2], h1p[3]}), (u32x4*)(hp + P.dff));
           }
           const u32x4 gv = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
           u32x4* gp = (u32x4*)((bf16_t*)P.C2 + (size_t)row * P.ldc2 + f0);
-          if (P.dbg & 128) {}
+          if (G8_DBG(128)) {}
           else if (P.nt_c & 2) __builtin_nontemporal_store(gv, gp);      // (h: only the backward reads it again; g: the next kernel)
           else *gp = gv;
         }
@@ -452,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
   auto kstep = [&](auto buf_tag, auto first_tag, bool second, bool last) {
     constexpr int buf = decltype(buf_tag)::value;
     constexpr bool first = decltype(first_tag)::value;
-    const bool full = c_m0 + BM <= row_limit(c_m0) && c_n0 >= c_cmin && !ACCUM && !(P.dbg & 1);
+    const bool full = c_m0 + BM <= row_limit(c_m0) && c_n0 >= c_cmin && !ACCUM && !(G8_DBG(1));
     const bool pf = p_pending && p_full;                      // the previous tile's batches were issued in full
     const int x4 = (last && full ? 2 : 0) + (first && pf ? 2 : 0);
     // ph1: r0 x c0
@@ -514,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
 int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        int out_dtype, int accumulate, hipStream_t s) {
   int min_m = 2048;
-  { const char* e = getenv("MRMT3_GEMM8_MIN_M"); if (e && atoi(e) >= 128) min_m = atoi(e); }      // tuning only
+  { const int e = MR_KNOB("MRMT3_GEMM8_MIN_M", 0); if (e >= 128) min_m = e; }      // tuning only
   if (M < min_m || N < 256 || N % 128 != 0 || K % 128 != 0 || K < 128) return 0;      // (an even number of K steps)
   // Which shapes: measured COLD (profiles/r03_gemm_ab_cold.txt: 512 MiB written before every launch, as inside the
   // training step — the back-to-back table of round 2 re-read operands out of the Infinity Cache and flattered round
@@ -523,8 +522,7 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
   // last wave's slots.  A last column tile that is half overlap (N = 384 / 1152: 11-33 % of the MFMAs redone) still
   // wins cold (qkv 115 -> 96 us).  Not: the accumulate form (one launch per decoder layer).
   {
-    const char* force = getenv("MRMT3_GEMM8_ALL");             // tuning: take every admissible shape
-    if (!(force && force[0] == '1')) {
+    if (MR_KNOB("MRMT3_GEMM8_ALL", 0) != 1) {                   // (1: tuning / tests, take every admissible shape)
       if (accumulate) return 0;
       const int cu = g8_cus() & ~7, tn = ceil_div(N, 256), t256 = ceil_div(M, 256) * tn;
       const int nt = t256 < cu ? ceil_div(M, 128) * tn : t256;
@@ -537,24 +535,27 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
   P.A = (const bf16_t*)A; P.B = (const bf16_t*)B; P.C = C;
   P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K;
   P.ksplit = 1; P.mpad = 0; P.kfull = K;
+  P.dbg = 0; P.skew_ticks = 0;
   P.nt_c = g8_store_mode();
   P.tiles_n = ceil_div(N, 256);
   const int cus = g8_cus() & ~7;
   const int tiles256 = ceil_div(M, 256) * P.tiles_n;
   const bool small = tiles256 < cus;                         // not enough 256-row tiles to fill the chip: 128-row tiles
   P.n_tiles = small ? ceil_div(M, 128) * P.tiles_n : tiles256;
+  int grid = P.n_tiles < cus ? ((P.n_tiles + 7) & ~7) : cus;
+  if (grid > P.n_tiles) grid = (P.n_tiles + 7) & ~7;
+#ifdef MRMT3_DIAG
   {
-    // one tile ~ nk x 1.4 us (0.7 for 128-row tiles) + the stores; eight start phases across that period
+    // (experiment, closed: start skew) one tile ~ nk x 1.4 us (0.7 for 128-row tiles) + the stores; eight start phases across that period
     P.dbg = mrmt3_diag_env("MRMT3_GEMM8_DBG");
-    static int skew_pct = -1;
-    if (skew_pct < 0) { const char* e = getenv("MRMT3_GEMM8_SKEW"); skew_pct = e ? atoi(e) : 0; }
+    const int skew_pct = MR_KNOB("MRMT3_GEMM8_SKEW", 0);
     const double tile_us = (K / 64) * (small ? 0.7 : 1.4) + 1.5;
     const int tiles_per_wg = ceil_div(P.n_tiles, cus);
     P.skew_ticks = tiles_per_wg >= 2 ? (int)(tile_us * 100.0 / 8.0 * skew_pct / 100.0) : 0;
+    const int g = MR_KNOB("MRMT3_GEMM8_GRID", 0);
+    if (g > 0 && g < grid) grid = g & ~7;
   }
-  int grid = P.n_tiles < cus ? ((P.n_tiles + 7) & ~7) : cus;
-  if (grid > P.n_tiles) grid = (P.n_tiles + 7) & ~7;
-  { const char* e = getenv("MRMT3_GEMM8_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e) & ~7; }   // diagnostics
+#endif
 #define G8_LAUNCH(TOUT, ACC)                                                                                     \
   do {                                                                                                           \
     if (small) hipLaunchKernelGGL((gemm_nt8_kernel<TOUT, ACC, 4>), dim3((unsigned)grid), dim3(512), 0, s, P);   \
@@ -575,8 +576,7 @@ int mrmt3_gemm_nt8_try(const void* A, int lda, const void* B, int ldb, void* C, 
 // [ksplit][mpad][N]) and one reduce pass sums the slabs in split order into C (bf16 or f32, += for the accumulate form):
 // a fixed summation order, no atomics.  mrmt3_gemm_nt_workspace_bytes() > 0 says when this pays.
 static int g8_splitk_plan(int M, int N, int K, int in_dtype) {
-  const char* e = getenv("MRMT3_GEMM8_SPLITK");              // tuning / A-B switch only
-  if (e && e[0] == '0') return 1;
+  if (MR_KNOB("MRMT3_GEMM8_SPLITK", 1) == 0) return 1;     // tuning / A-B switch only
   // The second launch and the slab round trip cost ~10 us: measured cold at 3072 rows (profiles/r03_gemm_splitk.txt)
   // K = 6144 98.8 -> 48.0 us and K = 2048 35.8 -> 29.6 us, but K = 1024 / 1152 22.8 -> 28.6 / 24.6 -> 27.9 us: only
   // from K = 2048, with >= 512 per split.
@@ -629,7 +629,9 @@ int mrmt3_gemm_nt8_splitk_try(const void* A, int lda, const void* B, int ldb, vo
   P.K = K / sp; P.kfull = K; P.ksplit = sp; P.mpad = mpad;
   P.tiles_n = ceil_div(N, 256);
   P.n_tiles = sp * (mpad / 128) * P.tiles_n;
+#ifdef MRMT3_DIAG
   P.dbg = mrmt3_diag_env("MRMT3_GEMM8_DBG");
+#endif
   const int grid = (P.n_tiles + 7) & ~7;
   hipLaunchKernelGGL((gemm_nt8_kernel<float, false, 4>), dim3((unsigned)grid), dim3(512), 0, s, P);
   const size_t total = (size_t)M * (N >> 2);
@@ -662,7 +664,7 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
                ldg % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wi % 16) == 0 && ((uintptr_t)h % 16) == 0 &&
                ((uintptr_t)g % 16) == 0 && ((size_t)rows * ldx + K) * 2 < 0x7FFF0000ull &&
                ((size_t)2 * dff * ldw + K) * 2 < 0x7FFF0000ull;
-  { const char* e = getenv("MRMT3_GEGLU_FUSED"); if (e && e[0] == '0') fused = false; }
+  if (MR_KNOB("MRMT3_GEGLU_FUSED", 1) == 0) fused = false;
   if (!fused) {
     int rc = mrmt3_gemm_nt(x, ldx, wi, ldw, h, ldh, rows, 2 * dff, K, MRMT3_BF16, MRMT3_BF16, 0, stream);
     if (rc != MRMT3_OK) return rc;
@@ -684,7 +686,10 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
   auto fill = [&](int nt) { return (double)nt / ((double)ceil_div(nt, cus) * cus); };
   const bool small = tiles256 < cus || (tiles256 < 4 * cus && fill(tiles128) > fill(tiles256) + 0.15);
   P.n_tiles = small ? tiles128 : tiles256;
+  P.dbg = 0;
+#ifdef MRMT3_DIAG
   P.dbg = mrmt3_diag_env("MRMT3_GEMM8_DBG");
+#endif
   P.skew_ticks = 0;
   int grid = P.n_tiles < cus ? ((P.n_tiles + 7) & ~7) : cus;
   if (small) hipLaunchKernelGGL((gemm_nt8_kernel<bf16_t, false, 4, 1>), dim3((unsigned)grid), dim3(512), 0, s, P);

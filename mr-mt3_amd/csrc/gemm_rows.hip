@@ -63,11 +63,19 @@ struct GRParams {
   int dff;
   DropCfg d0, d1;          // ADDNORM: d0 mask of y, d1 mask of the output (out_drop);  NORMBWD: d0 mask of dy;  GEGLUBWD: d0
   int out_drop, cache_mode;
+#ifdef MRMT3_DIAG
+  // The round-4 experiments (measured and closed) live in the diagnostics build only, libmrmt3_hip_diag.so:
   int skew_fine;           // start delay (10-ns ticks of s_memrealtime): see the kernel
-  unsigned long long* trace;   // diagnostics (mrmt3_gemm_rows_trace): 8 timestamps per workgroup
-  int dbg;                 // diagnostics (MRMT3_ROWS_DBG): 1 no K loop, 2 no row epilogue, 4 print the occupancy, 8 L2 prefetch of the activation tile,
-                           // 16 / 32 weight / activation loads switched off (zero fill), 64 no MFMAs, 128 no fragment reads
+  unsigned long long* trace;   // mrmt3_gemm_rows_trace: 8 timestamps per workgroup
+  int dbg;                 // MRMT3_ROWS_DBG: 1 no K loop, 2 no row epilogue, 4 print the occupancy, 16 / 32 weight / activation loads
+                           // switched off (zero fill), 64 no MFMAs, 128 no fragment reads, 256 K chunks walked from a per-workgroup start
+#endif
 };
+#ifdef MRMT3_DIAG
+#define GR_DBG(bit) (P.dbg & (bit))
+#else
+#define GR_DBG(bit) 0
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gr_rsrc(const void* base, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
     nt = (int)blockIdx.x - mt * P.n_ctiles;
   }
   const int m0 = mt * BM, n0 = nt * 512;
+#ifdef MRMT3_DIAG
 #define GR_STAMP(i) do { if (P.trace && tid == 0) P.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GR_STAMP(0);
   // (experiment, MRMT3_ROWS_SKEW_FINE: two start phases so that not every CU is in its K loop — HBM idle — and then in
@@ -147,6 +156,9 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
       while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
     }
   }
+#else
+#define GR_STAMP(i) do { } while (0)
+#endif
   if (EPI == GR_NORMBWD && P.dw_counters != nullptr && blockIdx.x == 0 && tid < 8) P.dw_counters[tid] = 0;
   if (m0 >= P.M) return;
 
@@ -166,7 +178,8 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
   const int qstride = 8 * P.ldb * 2, astride = 64 * P.lda * 2;
   unsigned char* const ldsA = lds + GR_B_BYTES + w * 1024;
   unsigned char* const ldsB = lds + w * 8192;
-  const int np = (P.dbg & 1) ? 0 : P.K >> 6;
+  const int np = GR_DBG(1) ? 0 : P.K >> 6;
+#ifdef MRMT3_DIAG
   // (experiment, MRMT3_ROWS_DBG bit 256: every workgroup walks the K chunks from a different starting chunk, so that the
   // CUs of an XCD do not all ask the L2 for the same weight lines at the same time)
   const int rot = (P.dbg & 256) && np > 0 ? (int)((blockIdx.x >> 3) % (unsigned)np) : 0;   // (blocks b, b + 8, ... share an XCD)
@@ -175,16 +188,19 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
     if (c >= np) c -= np;
     return c * 128;
   };
+#else
+  auto koff = [&](int chunk) __attribute__((always_inline)) -> int { return chunk * 128; };
+#endif
 
   auto ldA = [&](int slot, int chunk) __attribute__((always_inline)) {
-    const bool on = chunk < np && !(P.dbg & 32);
+    const bool on = chunk < np && !GR_DBG(32);
 #pragma unroll
     for (int q = 0; q < NAP; ++q)
       gr_dma16(ra, ldsA + slot * A_SLOT + q * 8192, voffA, on ? koff(chunk) + q * astride : GR_OOB);
   };
   // B of K chunk `chunk` (64 deep), column half ch -> this wave's slot ch
   auto ldB = [&](int ch, int chunk) __attribute__((always_inline)) {
-    const bool on = chunk < np && !(P.dbg & 16);
+    const bool on = chunk < np && !GR_DBG(16);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       gr_dma16(rb, ldsB + ch * 4096 + q * 1024, voffB, on ? koff(chunk) + (ch * 4 + q) * qstride : GR_OOB);
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
       const int fo = ks ? (f_off ^ 64) : f_off;     // (an integer offset: XOR on the pointer itself turns the reads into flat loads)
       const unsigned char* pa = lds + GR_B_BYTES + aslot * A_SLOT + fo;
       const unsigned char* pb = lds + w * 8192 + ch * 4096 + fo;
-      if (!(P.dbg & 128)) {
+      if (!GR_DBG(128)) {
 #pragma unroll
         for (int i = 0; i < RT; ++i) af[i] = *(const bf16x8*)(pa + i * 2048);
 #pragma unroll
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
         ldB(ch, p + 1);                            // this wave's own slot: its reads above have completed
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (!(P.dbg & 64)) {
+      if (!GR_DBG(64)) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
   __syncthreads();
 
   GR_STAMP(3);
-  if (P.dbg & 2) return;
+  if (GR_DBG(2)) return;
   // ---- rows: wave w takes tile rows w, w + 8, ...
   if constexpr (EPI == GR_ADDNORM) {
     // The stand-alone row kernel hides its per-row dependency chains (LDS read -> mask -> sum of squares -> six shuffle
@@ -507,15 +523,13 @@ __global__ __launch_bounds__(512, BM == 64 ? 4 : 2) void gemm_rows_kernel(GRPara
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
+#ifdef MRMT3_DIAG
 static unsigned long long* g_rows_trace = nullptr;
-// Diagnostics: per-workgroup timestamps (s_memrealtime, 10-ns ticks) of the fused kernels' phases are written to `buf`
-// ([grid][8] uint64: start, K loop start, K loop end, tile image written, end) until it is set back to NULL.
+// Diagnostics build only (not in include/mrmt3_hip.h): per-workgroup timestamps (s_memrealtime, 10-ns ticks) of the fused
+// kernels' phases are written to `buf` ([grid][8] uint64: start, K loop start, K loop end, tile image written, end) until
+// it is set back to NULL.
 extern "C" int mrmt3_gemm_rows_trace(void* buf) { g_rows_trace = (unsigned long long*)buf; return MRMT3_OK; }
-
-static int gr_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
+#endif
 
 // 1 when the fused kernel takes (M rows, N = n_ctiles * 512 columns, K): 16-byte aligned rows, K a multiple of 128 (an
 // even number of 64-deep pairs), every buffer offset below 2^31.
@@ -541,7 +555,7 @@ static int gr_cus() {
 // which is what the 64-row K loop ran at) once there are enough of them to fill the chip, else 64 rows (two per CU).
 // A function of the row count alone: the norm-weight partial rows (one per tile) follow it.  MRMT3_ROWS_BM forces one.
 static int gr_bm(int rows) {
-  const int f = gr_env("MRMT3_ROWS_BM", 0);
+  const int f = MR_KNOB("MRMT3_ROWS_BM", 0);
   if (f == 64 || f == 128) return f;
   return ceil_div(rows, 128) >= gr_cus() ? 128 : 64;
 }
@@ -555,9 +569,10 @@ static unsigned gr_grid(int M, int n_ctiles, int bm) {
 static void gr_base(GRParams& P, const void* A, int lda, const void* W, int ldw, int M, int K, int n_ctiles) {
   memset(&P, 0, sizeof(P));
   P.A = (const bf16_t*)A; P.B = (const bf16_t*)W; P.lda = lda; P.ldb = ldw; P.M = M; P.K = K; P.n_ctiles = n_ctiles;
+#ifdef MRMT3_DIAG
   P.dbg = mrmt3_diag_env("MRMT3_ROWS_DBG");
   P.trace = g_rows_trace;
-  P.skew_fine = gr_env("MRMT3_ROWS_SKEW_FINE", 0) / 10;
+  P.skew_fine = MR_KNOB("MRMT3_ROWS_SKEW_FINE", 0) / 10;
   if (P.dbg & 4) {
     int n64 = -1, n128 = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n64, gemm_rows_kernel<GR_ADDNORM, false, false, 64>, 512, 0);
@@ -565,6 +580,7 @@ static void gr_base(GRParams& P, const void* A, int lda, const void* W, int ldw,
     fprintf(stderr, "gemm_rows: workgroups per CU: %d (64-row tiles, LDS %d B), %d (128-row tiles, LDS %d B)\n", n64,
             GRCfg<64>::LDS, n128, GRCfg<128>::LDS);
   }
+#endif
 }
 #define GR_LAUNCH(EPI, RI, RO, rows, nct)                                                                                      \
   do {                                                                                                                         \
@@ -588,7 +604,7 @@ extern "C" int mrmt3_gemm_nt_addnorm(const void* A, int lda, const void* W, int 
   P.d0 = make_drop(p_drop, seed, stream_y, step_dev);
   P.d1 = make_drop(p_drop, seed, stream_out, step_dev);
   P.out_drop = out_drop;
-  P.cache_mode = gr_env("MRMT3_NORM_NT", 3);             // the stand-alone kernel's switch: streaming x0 load / x1 store
+  P.cache_mode = MR_KNOB("MRMT3_NORM_NT", 3);             // the stand-alone kernel's switch: streaming x0 load / x1 store
   GR_LAUNCH(GR_ADDNORM, false, false, rows, 1);
   MR_CHECK_LAUNCH("gemm_nt_addnorm");
   mrmt3_count(MRMT3_CNT_GEMM_NT_ADDNORM);
@@ -636,7 +652,7 @@ extern "C" int mrmt3_gemm_nt_geglubwd(const void* dy, int ldy, const void* WT, i
   gr_base(P, dy, ldy, WT, ldw, rows, K, dff / 512);
   P.h = (const bf16_t*)h; P.dh = (bf16_t*)dh; P.dff = dff;
   P.d0 = make_drop(p_drop, seed, stream_id, step_dev);
-  P.cache_mode = gr_env("MRMT3_GEGLUB_NT", 0);
+  P.cache_mode = MR_KNOB("MRMT3_GEGLUB_NT", 0);
   GR_LAUNCH(GR_GEGLUBWD, false, false, rows, dff / 512);
   MR_CHECK_LAUNCH("gemm_nt_geglubwd");
   mrmt3_count(MRMT3_CNT_GEMM_NT_GEGLUBWD);

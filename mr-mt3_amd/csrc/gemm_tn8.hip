@@ -342,8 +342,7 @@ int mrmt3_tn8_plan(int M, int N1, int N2, int* tiles, int* splits, int* rows_per
   // Shapes this kernel is measured to win on (profiles/r02_gemm_tn_ab.txt: w_wi x1.64, w_lm x1.72, w_wo x1.30,
   // w_qkv x1.22, e_wi x1.13): the chip is filled (>= 90 % of the CUs get a workgroup) and at most 15 % of the MFMAs go
   // to the overlap of a shifted last tile (N = 384 would redo a third).  MRMT3_TN8_ALL=1 (tuning) takes every shape.
-  const char* force = getenv("MRMT3_TN8_ALL");
-  if (!(force && force[0] == '1')) {
+  if (MR_KNOB("MRMT3_TN8_ALL", 0) != 1) {
     if (t * sp * 10 < cus * 9) return 0;
     if ((double)(ceil_div(N1, 256) * 256) * (ceil_div(N2, 256) * 256) > 1.15 * (double)N1 * N2) return 0;
   }
@@ -372,7 +371,7 @@ static int t8_cus() {
     if (hw <= 0) hw = 256;
   }
   int cus = hw;
-  { const char* e = getenv("MRMT3_TN_GROUP_CTAS"); if (e && atoi(e) >= 8) cus = atoi(e); }   // tests / tuning
+  { const int e = MR_KNOB("MRMT3_TN_GROUP_CTAS", 0); if (e >= 8) cus = e; }   // tests / tuning
   return cus & ~7;
 }
 

@@ -246,7 +246,9 @@ __global__ __launch_bounds__(LMW_THREADS, 2) void logmel_wave_kernel(
     for (int i = tid; i < CFFT_N; i += LMW_THREADS) twl[i] = ((const c2*)twid)[i];
     for (int i = tid; i < max_taps * 512; i += LMW_THREADS) {     // coalesced read of [mel][tap], transposed into LDS
       const int m = i / max_taps, q = i - m * max_taps;
-      fbt[q * 512 + m] = fb_w[i];
+      // taps at and beyond fb_cnt[m] count as zero whatever the caller left there (the header's contract: sum over
+      // q < fb_cnt[m]); masked here, once per workgroup, so the mel loop below can run all max_taps taps unconditionally
+      fbt[q * 512 + m] = q < fb_cnt[m] ? fb_w[i] : 0.f;
     }
   }
   __syncthreads();
@@ -266,6 +268,11 @@ __global__ __launch_bounds__(LMW_THREADS, 2) void logmel_wave_kernel(
     const u32x4 s0 = *(const u32x4*)(fb_start + 8 * lane), s1 = *(const u32x4*)(fb_start + 8 * lane + 4);
     fs[0] = (int)s0.x; fs[1] = (int)s0.y; fs[2] = (int)s0.z; fs[3] = (int)s0.w;
     fs[4] = (int)s1.x; fs[5] = (int)s1.y; fs[6] = (int)s1.z; fs[7] = (int)s1.w;
+    // a (zero-weight) padded tap reads mag[fb_start + q], q < max_taps <= LMW_MAX_TAPS: bins 0..1024 and the 63 zeros
+    // behind them.  A start outside [0, 1024] is not a filter of a 1025-bin spectrum: clamped, so that no LDS read leaves
+    // the wave's buffer whatever the table holds.
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fs[e] = min(max(fs[e], 0), CFFT_N);
   }
 
   c2* const wb = (c2*)(wbase + w * LMW_WBUF_BYTES);
@@ -406,8 +413,9 @@ static int logmel_launch(const float* audio, int batch, int n_samples, int hop, 
   {
     // the wave-per-frame kernel: the model's 512 mel bins, filters of at most LMW_MAX_TAPS taps, a hop that leaves room
     // for at least one frame's samples in the strip (MRMT3_LOGMEL=0: the round-1 kernel, A/B and parity)
-    const char* e = getenv("MRMT3_LOGMEL");
-    const bool fast = !(e && e[0] == '0') && n_mels == 512 && max_taps <= LMW_MAX_TAPS && hop % 2 == 0 && hop >= 2;
+    // ... and tables it may read as vectors: fb_start in 16-byte pieces, the window as float2, 16-byte output rows
+    const bool fast = MR_KNOB("MRMT3_LOGMEL", 1) != 0 && n_mels == 512 && max_taps <= LMW_MAX_TAPS && hop % 2 == 0 && hop >= 2 &&
+                      ((uintptr_t)fb_start % 16) == 0 && ((uintptr_t)window % 8) == 0 && ((uintptr_t)out % 16) == 0;
     if (fast) {
       // frames per workgroup: up to 64 (8 per wave), fewer for small batches so that the grid still covers the CUs —
       // a workgroup's waves walk their frames one after the other (12 segments: 16 frames each, 1 segment: 8)

@@ -48,10 +48,6 @@ template <> __device__ __forceinline__ void store4_nt<float>(float* p, const flo
 template <> __device__ __forceinline__ void store4_nt<bf16_t>(bf16_t* p, const float v[4]) {
   __builtin_nontemporal_store((u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}), (u32x2*)p);
 }
-static inline int cache_mode_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 
 // ------------------------------------------------------------------------------------------------
 // fused add + dropout + RMS norm, forward.   one wave per row, 4 rows per workgroup
@@ -133,7 +129,7 @@ extern "C" int mrmt3_add_rmsnorm_fwd(const float* x0, const void* y, int y_dtype
   hipStream_t s = (hipStream_t)stream;
   // bit 0: streaming store of the residual stream x1 (its reader is the next norm, three kernels on), bit 1: streaming
   // load of x0.  64 segments, same box, three alternations: 0 26.00 ms, 1 25.81, 2 25.97, 3 25.79 (MRMT3_NORM_NT)
-  const int cache_mode = cache_mode_env("MRMT3_NORM_NT", 3);
+  const int cache_mode = MR_KNOB("MRMT3_NORM_NT", 3);
 #define LAUNCH2(TY, TN, NV)                                                                                 \
   hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<TY, TN, NV>), grid, block, 0, s, x0, (const TY*)y, w, eps, x1, \
                      (TN*)xn, rstd, rows, cols, dy, dn, out_drop, cache_mode)
@@ -375,7 +371,7 @@ extern "C" int mrmt3_add_rmsnorm_bwd(const void* dxn, int dxn_dtype, const void*
   // bit 0: streaming load of x1 (the saved residual stream: read once), bit 1: streaming store of dx1 (the residual
   // gradient: its reader is the next norm backward), bit 2: streaming load of dres (MRMT3_NORMB_NT).  Measured: none of
   // them moves the 64-segment step (25.61-25.80 ms against 25.61-25.68, two alternations) — off.
-  const int cache_mode = cache_mode_env("MRMT3_NORMB_NT", 0);
+  const int cache_mode = MR_KNOB("MRMT3_NORMB_NT", 0);
 #define LAUNCH3(NV, TG, TRI, TRO)                                                                                 \
   hipLaunchKernelGGL((add_rmsnorm_bwd_kernel<NV, TG, TRI, TRO>), dim3((unsigned)ceil_div(rows, nbr)), dim3(256), 0, \
                      (hipStream_t)stream, (const TG*)dxn, (const TRI*)dres, x1, rstd, w, (TRO*)dx1, (bf16_t*)dy_bf16,  \
@@ -517,7 +513,7 @@ extern "C" int mrmt3_geglu_bwd(const void* h, const void* dg, void* dh, int rows
                                uint64_t seed, const int32_t* step_dev, uint32_t stream_id, void* stream) {
   MR_CHECK_ARG(h && dg && dh && rows > 0 && dff % 8 == 0, "geglu_bwd: bad args");
   DropCfg d = make_drop(p_drop, seed, stream_id, step_dev);
-  const int cm = cache_mode_env("MRMT3_GEGLUB_NT", 0);      // bit 0: streaming load of h (measured: no change; off)
+  const int cm = MR_KNOB("MRMT3_GEGLUB_NT", 0);      // bit 0: streaming load of h (measured: no change; off)
   if (dtype == MRMT3_F32)
     hipLaunchKernelGGL(geglu_bwd_kernel<float>, dim3(ew_blocks((size_t)rows * dff / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)h, (const float*)dg, (float*)dh, rows, dff, d, cm);

@@ -178,6 +178,14 @@ class GradBuckets:
         with torch.cuda.stream(stream):
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def comm(self):
+        """The library's own RCCL communicator (created on first use: every rank must get here together)."""
+        return self._native_comm()
+
+    def collective_stream(self, device):
+        """The stream the buckets' collectives run on (never the compute stream)."""
+        return self._launch_stream(device)
+
     def _launch_stream(self, device):
         if self._launch is None or self._launch.device != device:
             self._launch = torch.cuda.Stream(device=device)

@@ -25,6 +25,8 @@ vp, ci, cf, cu64, cu32, csz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_ui
 _SIGS = {
     "mrmt3_version": (ci, []),
     "mrmt3_last_error": (C.c_char_p, []),
+    "mrmt3_set_knob": (ci, [C.c_char_p, ci]),
+    "mrmt3_reset_knobs": (ci, []),
     "mrmt3_logmel_fwd": (ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp]),
     "mrmt3_logmel_crops_fwd": (ci, [vp, C.c_longlong, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp]),
     "mrmt3_gemm_nt": (ci, [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]),
@@ -46,7 +48,6 @@ _SIGS = {
     "mrmt3_geglu_fwd": (ci, [vp, vp, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_gemm_nt_geglu": (ci, [vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, cf, cu64, vp, cu32, vp]),
     "mrmt3_gemm_rows_ok": (ci, [ci, ci, ci, ci, ci]),
-    "mrmt3_gemm_rows_trace": (ci, [vp]),
     "mrmt3_gemm_nt_addnorm": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, cf, vp, vp, vp, cf, cu64, vp, cu32, cu32, ci, vp]),
     "mrmt3_gemm_nt_normbwd_partial_rows": (ci, [ci]),
     "mrmt3_gemm_nt_normbwd": (ci, [vp, ci, vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, ci, vp, cf, cu64, vp, cu32, vp, csz, vp]),
@@ -88,6 +89,8 @@ _SIGS = {
     "mrmt3_comm_create": (ci, [vp, ci, ci, C.POINTER(vp)]),
     "mrmt3_comm_destroy": (ci, [vp]),
     "mrmt3_allreduce": (ci, [vp, vp, csz, ci, ci, vp]),
+    "mrmt3_flag_signal": (ci, [vp, vp]),
+    "mrmt3_flag_wait": (ci, [vp, vp, vp, ci, vp]),
 }
 
 
@@ -98,13 +101,15 @@ def header_symbols(path: str = HEADER_PATH):
     return sorted(set(re.findall(r"\b(mrmt3_[a-z0-9_]+)\s*\(", txt)))
 
 
-def build(verbose: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into libmrmt3_hip.so (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC_DIR, "-j8"], capture_output=True, text=True)
-    if verbose or r.returncode != 0:
-        print(r.stdout[-4000:], r.stderr[-4000:])
-    if r.returncode != 0:
-        raise RuntimeError("building libmrmt3_hip.so failed")
+def build(verbose: bool = False, diag: bool = True) -> str:
+    """Compile csrc/*.hip for gfx950 into libmrmt3_hip.so (hipcc cross-compiles without a GPU) and, with `diag`, the
+    -DMRMT3_DIAG twin libmrmt3_hip_diag.so that profiles/tools load (never the product path)."""
+    for target in (["all"], ["diag"]) if diag else (["all"],):
+        r = subprocess.run(["make", "-C", CSRC_DIR, "-j8"] + target, capture_output=True, text=True)
+        if verbose or r.returncode != 0:
+            print(r.stdout[-4000:], r.stderr[-4000:])
+        if r.returncode != 0:
+            raise RuntimeError("building libmrmt3_hip.so failed (make %s)" % target[0])
     return LIB_PATH
 
 
@@ -130,10 +135,22 @@ def load():
     return lib
 
 
-MIN_VERSION = 107
+MIN_VERSION = 108
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
                  "gemm_nt_geglubwd")
+
+
+def set_knob(name: str, value: int):
+    """Override a dispatch / tuning switch of the C library in-process (mrmt3_set_knob): `name` is the environment
+    variable's name (MRMT3_ROWS_BM, MRMT3_GEMM8, ...), `value` the integer it would hold.  The library reads its knobs from
+    the environment once per process; tests and tuning tools switch them through this call."""
+    _check(load().mrmt3_set_knob(name.encode(), int(value)), "set_knob")
+
+
+def reset_knobs():
+    """Drop every override; each knob is re-read from the environment at its next use."""
+    _check(load().mrmt3_reset_knobs(), "reset_knobs")
 
 
 def dispatch_counts(reset: bool = False) -> dict:
@@ -945,3 +962,19 @@ class Comm:
         if self._h:
             h, self._h = self._h, vp()
             _check(load().mrmt3_comm_destroy(h), "comm_destroy")
+
+
+def flag_signal(flag: torch.Tensor, stream=None):
+    """flag[0] += 1 behind everything enqueued so far on `stream` (default: the current one) — mrmt3_flag_signal."""
+    _dev(flag)
+    assert flag.dtype == torch.int32 and flag.numel() >= 1
+    s = C.c_void_p((stream or torch.cuda.current_stream(flag.device)).cuda_stream)
+    _check(load().mrmt3_flag_signal(_p(flag), s), "flag_signal")
+
+
+def flag_wait(flag: torch.Tensor, seen: torch.Tensor, err: torch.Tensor, timeout_ms: int = 5000, stream=None):
+    """`stream` waits until flag[0] >= seen[0] + 1, then seen[0] += 1; err[0] = 1 after `timeout_ms` without the signal."""
+    _dev(flag, seen, err)
+    assert flag.dtype == seen.dtype == err.dtype == torch.int32
+    s = C.c_void_p((stream or torch.cuda.current_stream(flag.device)).cuda_stream)
+    _check(load().mrmt3_flag_wait(_p(flag), _p(seen), _p(err), int(timeout_ms), s), "flag_wait")

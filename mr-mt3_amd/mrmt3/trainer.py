@@ -17,7 +17,16 @@ to the eager step bit for bit:
   * inputs are copied into static buffers the captured kernels read.
 With more than one rank the step is cut into one graph per gradient bucket: the RCCL all-reduce of a finished bucket
 is enqueued EAGERLY between two replays on the launch stream, so it still overlaps the rest of backward and no
-collective is ever captured.
+collective is ever captured.  That is the default, because it is the form that needs nothing from RCCL but a plain call.
+
+MRMT3_DDP_GRAPH=1 (round 5) captures the collectives too, as TWO graphs replayed side by side on two streams: the whole
+compute step as one chain (no segment per bucket: a bucket boundary costs 0.07 ms, profiles/r04_bucket_boundary_cost.txt)
+and the buckets' all-reduces (mrmt3_allreduce on the library's own RCCL communicator) as a second chain on the
+collective stream.  The two talk through counting flags in device memory (mrmt3_flag_signal / mrmt3_flag_wait,
+csrc/comm.hip): "bucket i complete" from the compute chain, "all reduced" back before AdamW.  Not one graph with a side
+branch — ROCm 7.2 replays forked graphs serially and slowly — and not the collectives in-line in the compute
+chain (MRMT3_DDP_GRAPH=inline builds that form for A/B): in-line, every all-reduce is exposed instead of hidden under
+the rest of backward.  If the capture of a collective fails the trainer falls back to the segmented form above.
 """
 from __future__ import annotations
 
@@ -36,6 +45,7 @@ class _CapturedStep:
 
     def __init__(self):
         self.segments, self.tail = [], None
+        self.comm = None          # two-graph form: the chain of all-reduces, replayed on the collective stream
         self.inputs = self.labels = self.prev = self.loss = None
 
 
@@ -74,6 +84,17 @@ class Trainer:
         # every dropout mask of a step is salted in-kernel by the device step counter (see module docstring)
         self.engine.step_dev = self.step_dev
         self.use_graph = (os.environ.get("MRMT3_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        # "" (default): one graph per gradient bucket, collectives eager between them; "1": two graphs side by side, the
+        # collectives captured (needs the f32 exchange and the library's own communicator); "inline": one graph, collectives
+        # in the compute chain (A/B only).  See the module docstring.
+        self.ddp_graph = os.environ.get("MRMT3_DDP_GRAPH", "")
+        if self.ddp_graph in ("0", "off"):
+            self.ddp_graph = ""
+        if self.ddp_graph and self.buckets.exchange_dtype is not None:
+            self.ddp_graph = ""                              # the compressed exchange stages copies around the collective
+        if self.ddp_graph and self.buckets.active:
+            self.buckets.native = True                       # the eager warm-up steps use the communicator the capture will
+        self._hand = None                                    # flags of the two-graph form (device int32): see _handoffs()
         self.graph_warmup = 2            # eager steps per input signature before capture (tables, workspaces)
         self._graphs = {}                # signature -> _CapturedStep
         self._eager_seen = {}
@@ -85,9 +106,10 @@ class Trainer:
         return sp.logmel_segments(audio, out_bf16=(self.engine.dt == torch.bfloat16))
 
     # ---- one step's device work (identical in eager mode, under capture and — by replay — afterwards) ------------
-    def _step_body(self, inputs, labels, targets_prev, audio, cut=None):
+    def _step_body(self, inputs, labels, targets_prev, audio, cut=None, before_optimizer=None):
         """Enqueues one optimizer step.  `cut(bucket_indices)` is called where a gradient bucket is complete (only
-        when collectives will run); under capture it closes the current graph segment."""
+        when collectives will run); under capture it closes the current graph segment (or, with the collectives
+        captured, signals the bucket to the collective graph).  `before_optimizer()` runs right before AdamW."""
         eng, flat = self.engine, self.flat
         eng.reset_deferred()                                 # nothing of an aborted capture / failed step leaks into this one
         eng._stream_ctr = 0                                  # dropout site ids are per-step (step_dev salts them)
@@ -118,6 +140,8 @@ class Trainer:
             active = self.buckets.active
             eng.backward(tape, dl, on_layer_done=layer_done if active else None)     # ends with join_wgrad()
             cut([j for j in range(len(self.buckets.buckets)) if j not in sent] if active else [])
+        if before_optimizer is not None:
+            before_optimizer()
         flat.adamw_step(self.lr_dev, self.step_dev, self.betas, self.eps, self.wd, grad_scale=1.0 / self.world)
         return loss
 
@@ -154,7 +178,20 @@ class Trainer:
                 self._eager_seen[sig] = seen + 1
                 return self._step_body(inputs, labels, targets_prev, audio)
             try:
-                cap = self._capture(sig, inputs, labels, targets_prev, audio)
+                try:
+                    cap = self._capture(sig, inputs, labels, targets_prev, audio)
+                except Exception as e:     # noqa: BLE001
+                    if not (self.ddp_graph and self.buckets.active):
+                        raise
+                    # the collectives would not capture: the segmented form (collectives eager between the segments)
+                    import warnings
+                    warnings.warn("capturing the gradient all-reduces failed (%s: %s); falling back to one graph per "
+                                  "bucket with eager collectives" % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+                    self.ddp_graph = ""
+                    self.engine.reset_deferred()
+                    self.engine._stream_ctr = 0
+                    torch.cuda.synchronize()
+                    cap = self._capture(sig, inputs, labels, targets_prev, audio)
             except Exception as e:     # noqa: BLE001 — whatever a capture trips over, the eager step is still correct
                 # (nothing executed during the failed capture: the step below is the first to run; the launches the
                 # aborted capture had deferred are dropped — _step_body starts with Engine.reset_deferred())
@@ -171,6 +208,10 @@ class Trainer:
         if cap.prev is not None:
             cap.prev.copy_(targets_prev, non_blocking=True)
         self.buckets.reset()
+        if cap.comm is not None:           # two graphs side by side; they order themselves through the hand-off flags
+            ks = self.buckets.collective_stream(cap.inputs.device)
+            with torch.cuda.stream(ks):
+                cap.comm.replay()
         for graph, fire in cap.segments:
             graph.replay()
             for idx in fire:
@@ -178,6 +219,26 @@ class Trainer:
         self.buckets.wait()
         cap.tail.replay()
         return cap.loss.clone()            # the graph's own loss scalar is overwritten by the next replay
+
+    # ---- the collectives captured: hand-off flags, the second graph ------------------------------------------------
+    def _handoffs(self, device):
+        """Device words of the two-graph form: flags[j] counts completions of bucket j (compute graph), flags[n] counts
+        "every bucket reduced" (collective graph); seen[] are the waiting sides' own counters; err is raised by a wait that
+        timed out (check_exchange())."""
+        if self._hand is None:
+            n = len(self.buckets.buckets) + 1
+            self._hand = dict(flags=torch.zeros(n, dtype=torch.int32, device=device),
+                              seen=torch.zeros(n, dtype=torch.int32, device=device),
+                              err=torch.zeros(1, dtype=torch.int32, device=device),
+                              timeout_ms=int(os.environ.get("MRMT3_DDP_GRAPH_TIMEOUT_MS", "20000")))
+        return self._hand
+
+    def check_exchange(self):
+        """Raises if a hand-off between the compute graph and the collective graph ever timed out (host sync: call it where
+        the host waits anyway — end of an epoch, a checkpoint, the end of a benchmark)."""
+        if self._hand is not None and int(self._hand["err"].item()) != 0:
+            raise RuntimeError("data-parallel step: a graph hand-off timed out (a gradient bucket was never signalled or "
+                               "never reduced); the gradients of that step are not the all-reduced ones")
 
     def _capture(self, sig, inputs, labels, targets_prev, audio):
         """Record the step once (nothing executes during capture); `train_step` then replays it, this step included."""
@@ -218,10 +279,31 @@ class Trainer:
         overlap_was = eng.overlap_wgrad
         if os.environ.get("MRMT3_GRAPH_LINEAR", "1") == "1":
             eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
+        mode = self.ddp_graph if self.buckets.active else ""
+        before_opt, order = None, []
+        if mode:
+            comm = self.buckets.comm()         # created (and used by the eager steps) before anything captures
+            G = self.flat.G
+            if mode == "inline":
+                def cut(fire):                 # noqa: F811 — the collective as a node of the compute chain itself
+                    for j in fire:
+                        b = self.buckets.buckets[j]
+                        comm.allreduce(G[b["start"]:b["end"]], stream=cs)
+            else:
+                hand = self._handoffs(cap.inputs.device)
+                n_b = len(self.buckets.buckets)
+
+                def cut(fire):                 # noqa: F811 — "bucket j is complete" to the collective graph
+                    for j in fire:
+                        lib.flag_signal(hand["flags"][j:j + 1], stream=cs)
+                        order.append(j)
+
+                def before_opt():
+                    lib.flag_wait(hand["flags"][n_b:], hand["seen"][n_b:], hand["err"], hand["timeout_ms"], stream=cs)
         with torch.cuda.stream(cs):
             begin()
             try:
-                cap.loss = self._step_body(cap.inputs, cap.labels, cap.prev, audio, cut=cut)
+                cap.loss = self._step_body(cap.inputs, cap.labels, cap.prev, audio, cut=cut, before_optimizer=before_opt)
                 state["g"].capture_end()
             except Exception:
                 try:
@@ -232,6 +314,25 @@ class Trainer:
             finally:
                 eng.overlap_wgrad = overlap_was
             cap.tail = state["g"]
+        if mode and mode != "inline":
+            # the second graph: for every bucket in the order backward completes them — wait for its signal, all-reduce it;
+            # then "all reduced" back to the compute chain
+            ks = self.buckets.collective_stream(cap.inputs.device)
+            ks.wait_stream(cs)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(ks):
+                g2.capture_begin(pool=pool if pool is not None else cap.tail.pool(), capture_error_mode="thread_local")
+                try:
+                    for j in order:
+                        b = self.buckets.buckets[j]
+                        lib.flag_wait(hand["flags"][j:j + 1], hand["seen"][j:j + 1], hand["err"], hand["timeout_ms"], stream=ks)
+                        comm.allreduce(G[b["start"]:b["end"]], stream=ks)
+                    lib.flag_signal(hand["flags"][n_b:], stream=ks)
+                finally:
+                    g2.capture_end()
+            assert sorted(order) == list(range(n_b)), order
+            cap.comm = g2
+            cs.wait_stream(ks)
         cur.wait_stream(cs)
         self._graphs[sig] = cap
         return cap

@@ -2,6 +2,8 @@
 over a K sweep at fixed M, N (slope = one K step, intercept = per-tile + per-launch overhead)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the kernel diagnostics this tool switches on exist in the -DMRMT3_DIAG build only (make -C mr-mt3_amd/csrc diag)
+os.environ.setdefault("MRMT3_TOOL_LIB", os.path.join(ROOT, "mr-mt3_amd", "mrmt3", "libmrmt3_hip_diag.so"))
 sys.path.insert(0, os.path.join(ROOT, "mr-mt3_amd"))
 import torch
 from mrmt3 import lib

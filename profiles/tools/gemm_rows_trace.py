@@ -5,6 +5,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the kernel diagnostics this tool switches on exist in the -DMRMT3_DIAG build only (make -C mr-mt3_amd/csrc diag)
+os.environ.setdefault("MRMT3_TOOL_LIB", os.path.join(ROOT, "mr-mt3_amd", "mrmt3", "libmrmt3_hip_diag.so"))
 sys.path.insert(0, os.path.join(ROOT, "mr-mt3_amd"))
 import numpy as np
 import torch
@@ -14,6 +16,8 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 dev = torch.device("cuda:0")
 L = lib.load()
+import ctypes
+L.mrmt3_gemm_rows_trace.restype, L.mrmt3_gemm_rows_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]   # (diagnostics build only: not in the header)
 PADW, PADA = int(os.environ.get("PADW", "0")), int(os.environ.get("PADA", "0"))
 a = torch.randn(M, K + PADA, device=dev).bfloat16()[:, :K]
 w = (torch.randn(512, K + PADW, device=dev) * K ** -0.5).bfloat16()[:, :K]

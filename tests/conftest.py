@@ -20,3 +20,39 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "model_golden.npz"))
+
+
+class _Knobs:
+    """Dispatch / tuning switches for the duration of one test: `set(name, value)` puts MRMT3_<name> into the environment
+    (for the Python readers: engine, trainer, ddp) AND overrides it in the C library (mrmt3_set_knob — the library reads
+    its knobs from the environment once per process, so a later setenv alone would not reach it)."""
+
+    def __init__(self, monkeypatch):
+        self.mp, self.values = monkeypatch, {}
+
+    def _apply(self):
+        from mrmt3 import lib
+        lib.reset_knobs()
+        for k, v in self.values.items():
+            try:
+                lib.set_knob(k, int(v))
+            except ValueError:
+                pass                              # not an integer switch: a Python-side variable only
+
+    def set(self, name, value):
+        self.mp.setenv(name, str(value))
+        self.values[name] = value
+        self._apply()
+
+    def unset(self, name):
+        self.mp.delenv(name, raising=False)
+        self.values.pop(name, None)
+        self._apply()
+
+
+@pytest.fixture
+def knobs(monkeypatch):
+    k = _Knobs(monkeypatch)
+    yield k
+    from mrmt3 import lib
+    lib.reset_knobs()                              # (the environment is restored by monkeypatch after this)

@@ -5,7 +5,11 @@ mrmt3_gemm_nt_geglubwd (wo data gradient -> gated-GELU backward).  The forward f
 SAME BITS as the two-kernel form (the tile is rounded to bf16 exactly as the stand-alone product writes it and the row
 arithmetic is restated in the same order); the norm backward promises the same bits for dx1 / dy and the same norm-weight
 gradient up to the grouping of its f32 partial sums (64 rows per partial row instead of 32).  Each case is also held to an
-f32 torch reference of the whole chain, so that the pair cannot be wrong together."""
+f32 torch reference of the whole chain, so that the pair cannot be wrong together.
+
+Every case runs under BOTH tile heights (the knob MRMT3_ROWS_BM = 64 / 128): the launch picks 128-row tiles by itself only
+from 32 641 rows on (one workgroup per CU), which is what the 64-segment benchmark step dispatches for the decoder's
+65 536 rows — the `*_at_the_benchmark_row_count` cases take that path WITHOUT the knob and assert that they did."""
 import pytest
 import torch
 
@@ -21,6 +25,14 @@ def lib():
     return L
 
 
+@pytest.fixture(params=[64, 128], ids=["tile64", "tile128"])
+def tile(request, knobs):
+    """Rows of the fused kernels' tile, forced (gemm_rows.hip: gr_bm): GRCfg<64> is 2 activation slots / one piece per wave /
+    8-row row phases, GRCfg<128> 4 slots / 2 pieces / 16-row row phases with other counted waits — separate instantiations."""
+    knobs.set("MRMT3_ROWS_BM", request.param)
+    return request.param
+
+
 def _rand(shape, scale, seed, dtype=torch.bfloat16):
     g = torch.Generator(device="cuda").manual_seed(seed)
     return (torch.randn(*shape, device="cuda", generator=g) * scale).to(dtype)
@@ -33,7 +45,7 @@ FWD_SHAPES = [(4096, 384), (4096, 1024), (1000, 384), (40, 128), (16384, 512)]
 @pytest.mark.parametrize("rows,K", FWD_SHAPES)
 @pytest.mark.parametrize("p", [0.0, 0.1])
 @pytest.mark.parametrize("out_drop", [False, True])
-def test_gemm_nt_addnorm_equals_the_two_kernels_bitwise(lib, rows, K, p, out_drop):
+def test_gemm_nt_addnorm_equals_the_two_kernels_bitwise(lib, tile, rows, K, p, out_drop):
     a = _rand((rows, K), 1.0, 1)
     w = _rand((512, K), K ** -0.5, 2)
     x0 = _rand((rows, 512), 1.0, 3, torch.float32)
@@ -60,7 +72,7 @@ def test_gemm_nt_addnorm_equals_the_two_kernels_bitwise(lib, rows, K, p, out_dro
         assert ((xn.float() - ref).norm() / ref.norm()).item() < 4e-3
 
 
-def test_gemm_nt_addnorm_in_place_residual_and_no_x1(lib):
+def test_gemm_nt_addnorm_in_place_residual_and_no_x1(lib, tile):
     rows, K = 2048, 384
     a, w = _rand((rows, K), 1.0, 4), _rand((512, K), K ** -0.5, 5)
     x0 = _rand((rows, 512), 1.0, 6, torch.float32)
@@ -81,7 +93,7 @@ BWD_SHAPES = [(4096, 1152), (4096, 384), (1000, 384), (16384, 2048), (72, 128)] 
 @pytest.mark.parametrize("res_in,res_out", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
                                             (torch.float32, torch.float32), (torch.float32, torch.bfloat16)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_gemm_nt_normbwd_equals_the_two_kernels(lib, rows, K, res_in, res_out, p):
+def test_gemm_nt_normbwd_equals_the_two_kernels(lib, tile, rows, K, res_in, res_out, p):
     a = _rand((rows, K), 1.0, 11)
     wt = _rand((512, K), K ** -0.5, 12)
     dres = _rand((rows, 512), 1.0, 13, res_in)
@@ -97,6 +109,7 @@ def test_gemm_nt_normbwd_equals_the_two_kernels(lib, rows, K, res_in, res_out, p
     before = lib.dispatch_counts()["gemm_nt_normbwd"]
     dx1, dy = lib.gemm_nt_normbwd(a, wt, dres, x1, rstd, wn, dw, dx1_dtype=res_out, **kw)
     assert lib.dispatch_counts()["gemm_nt_normbwd"] == before + 1
+    assert lib.load().mrmt3_gemm_nt_normbwd_partial_rows(rows) == -(-rows // tile)
     torch.cuda.synchronize()
     assert dx1.dtype == res_out and torch.equal(dx1, dx1_ref), (dx1.float() - dx1_ref.float()).abs().max().item()
     assert torch.equal(dy.view(torch.int16), dy_ref.view(torch.int16))
@@ -117,7 +130,7 @@ def test_gemm_nt_normbwd_equals_the_two_kernels(lib, rows, K, res_in, res_out, p
         assert ((dw - dwf).norm() / dwf.norm()).item() < 3e-3
 
 
-def test_gemm_nt_normbwd_partial_rows_feed_the_batched_reduce(lib):
+def test_gemm_nt_normbwd_partial_rows_feed_the_batched_reduce(lib, tile):
     """The engine's form: several sites leave their partial rows, ONE mrmt3_norm_dw_reduce sums them (a fused site next to
     a stand-alone site in the same batch)."""
     rows, K = 4096, 384
@@ -146,7 +159,7 @@ def test_gemm_nt_normbwd_partial_rows_feed_the_batched_reduce(lib):
 
 @pytest.mark.parametrize("rows", [4096, 1000, 24])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_gemm_nt_geglubwd_equals_the_two_kernels_bitwise(lib, rows, p):
+def test_gemm_nt_geglubwd_equals_the_two_kernels_bitwise(lib, tile, rows, p):
     d, dff = 512, 1024
     dy = _rand((rows, d), 1.0, 41)
     wt = _rand((dff, d), d ** -0.5, 42)                     # wo^T
@@ -160,6 +173,95 @@ def test_gemm_nt_geglubwd_equals_the_two_kernels_bitwise(lib, rows, p):
     assert lib.dispatch_counts()["gemm_nt_geglubwd"] == before + 1
     torch.cuda.synchronize()
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (got.float() - ref.float()).abs().max().item()
+    if p == 0.0:
+        hf = h.float().requires_grad_(True)
+        g = torch.nn.functional.gelu(hf[:, :dff], approximate="tanh") * hf[:, dff:]
+        g.backward((dy.float() @ wt.float().t()).bfloat16().float())
+        assert ((got.float() - hf.grad).norm() / hf.grad.norm()).item() < 4e-3
+
+
+# ---- the benchmark's own row count: 64 segments x 1024 tokens, tile height chosen by the launch itself ------------------
+
+BENCH_ROWS = 65536
+
+
+def _took_128_row_tiles(lib):
+    """The launch's own choice at BENCH_ROWS rows (no knob): 128-row tiles once ceil(rows / 128) reaches the CU count."""
+    return lib.load().mrmt3_gemm_nt_normbwd_partial_rows(BENCH_ROWS) == BENCH_ROWS // 128
+
+
+@pytest.mark.parametrize("K", [384, 1024])          # o / co projection, wo
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gemm_nt_addnorm_at_the_benchmark_row_count(lib, knobs, K, p):
+    knobs.unset("MRMT3_ROWS_BM")
+    assert _took_128_row_tiles(lib), "a 256-CU MI355X runs 65 536 rows as 512 tiles of 128 rows"
+    rows = BENCH_ROWS
+    a, w = _rand((rows, K), 1.0, 51), _rand((512, K), K ** -0.5, 52)
+    x0 = _rand((rows, 512), 1.0, 53, torch.float32)
+    wn = (1.0 + 0.1 * torch.randn(512, device="cuda")).float()
+    step = torch.tensor([9], device="cuda", dtype=torch.int32)
+    kw = dict(p=p, seed=365, stream_y=5, stream_out=6, out_drop=True, step=step)
+    y = lib.gemm_nt(a, w, out_dtype=torch.bfloat16)
+    x1_ref, xn_ref, rstd_ref = lib.add_rmsnorm_fwd(x0, y, wn, 1e-6, torch.bfloat16, **kw)
+    x1, xn, rstd = lib.gemm_nt_addnorm(a, w, x0, wn, 1e-6, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x1_ref) and torch.equal(rstd, rstd_ref) and torch.equal(xn.view(torch.int16), xn_ref.view(torch.int16))
+    if p == 0.0:
+        yf = (a.float() @ w.float().t()).bfloat16().float()
+        xf = x0 + yf
+        ref = wn * xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-6)
+        assert (x1 - xf).abs().max().item() <= 2.0 ** -7 * max(1.0, yf.abs().max().item())
+        assert ((xn.float() - ref).norm() / ref.norm()).item() < 4e-3
+
+
+@pytest.mark.parametrize("K", [384, 1152, 512])     # d_cq, d_qkv, and a K the engine sends to the ping-pong product today
+@pytest.mark.parametrize("res", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gemm_nt_normbwd_at_the_benchmark_row_count(lib, knobs, K, res, p):
+    knobs.unset("MRMT3_ROWS_BM")
+    assert _took_128_row_tiles(lib)
+    rows = BENCH_ROWS
+    a, wt = _rand((rows, K), 1.0, 61), _rand((512, K), K ** -0.5, 62)
+    dres = _rand((rows, 512), 1.0, 63, res)
+    x1 = _rand((rows, 512), 1.5, 64, torch.float32)
+    rstd = torch.rsqrt((x1 * x1).mean(-1) + 1e-6)
+    wn = (1.0 + 0.1 * torch.randn(512, device="cuda")).float()
+    step = torch.tensor([4], device="cuda", dtype=torch.int32)
+    kw = dict(p=p, seed=99, stream_y=21, step=step)
+    dxn = lib.gemm_nt(a, wt, out_dtype=torch.bfloat16)
+    dw_ref, dw = torch.zeros(512, device="cuda"), torch.zeros(512, device="cuda")
+    dx1_ref, dy_ref = lib.add_rmsnorm_bwd(dxn, dres, x1, rstd, wn, dw_ref, dx1_dtype=res, **kw)
+    before = lib.dispatch_counts()["gemm_nt_normbwd"]
+    dx1, dy = lib.gemm_nt_normbwd(a, wt, dres, x1, rstd, wn, dw, dx1_dtype=res, **kw)
+    assert lib.dispatch_counts()["gemm_nt_normbwd"] == before + 1
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx1_ref) and torch.equal(dy.view(torch.int16), dy_ref.view(torch.int16))
+    assert (dw - dw_ref).abs().max().item() <= 2e-5 * dw_ref.abs().max().item() + 1e-6
+    if p == 0.0 and res == torch.float32:
+        g = (a.float() @ wt.float().t()).bfloat16().float()
+        xh = x1 * rstd[:, None]
+        gw = g * wn
+        ref = rstd[:, None] * (gw - xh * (gw * xh).mean(-1, keepdim=True)) + dres.float()
+        assert ((dx1 - ref).norm() / ref.norm()).item() < 3e-3
+        dwf = (g * xh).sum(0)
+        assert ((dw - dwf).norm() / dwf.norm()).item() < 3e-3
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gemm_nt_geglubwd_at_the_benchmark_row_count(lib, knobs, p):
+    knobs.unset("MRMT3_ROWS_BM")
+    assert _took_128_row_tiles(lib)
+    rows, d, dff = BENCH_ROWS, 512, 1024
+    dy, wt = _rand((rows, d), 1.0, 71), _rand((dff, d), d ** -0.5, 72)
+    h = _rand((rows, 2 * dff), 1.0, 73)
+    step = torch.tensor([5], device="cuda", dtype=torch.int32)
+    kw = dict(p=p, seed=7, stream_id=17, step=step)
+    ref = lib.geglu_bwd(h, lib.gemm_nt(dy, wt, out_dtype=torch.bfloat16), **kw)
+    before = lib.dispatch_counts()["gemm_nt_geglubwd"]
+    got = lib.gemm_nt_geglubwd(dy, wt, h, **kw)
+    assert lib.dispatch_counts()["gemm_nt_geglubwd"] == before + 1
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
     if p == 0.0:
         hf = h.float().requires_grad_(True)
         g = torch.nn.functional.gelu(hf[:, :dff], approximate="tanh") * hf[:, dff:]

@@ -67,7 +67,44 @@ def test_logmel_edge_cases(dev):
     np.testing.assert_allclose(gb, logmel_ref.logmel_segments(x[:, :32768]), atol=4e-3, rtol=0)
 
 
-def test_logmel_wave_kernel_matches_the_round1_kernel(dev, monkeypatch):
+def test_logmel_ignores_filter_taps_beyond_fb_cnt_and_takes_unaligned_tables(dev, knobs):
+    """include/mrmt3_hip.h: filter m = sum over q < fb_cnt[m]; whatever fb_w holds behind a filter's last tap (NaN,
+    garbage: a C-ABI caller need not zero-pad) is never used — by either kernel.  Tables that are not
+    aligned for the wave-per-frame kernel's vector reads go to the general kernel, same numbers."""
+    from contrib import spectrograms as sp
+    from mrmt3 import lib
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.uniform(-1, 1, size=(3, 32768)).astype(np.float32)).to(dev)
+    t = dict(sp.kernel_tables(sp.SpectrogramConfig(), dev))
+    want = lib.logmel(x, t)
+    bad = dict(t)
+    w = t["fb_w"].clone()
+    q = torch.arange(t["max_taps"], device=dev)[None, :]
+    tail = q >= t["fb_cnt"][:, None]
+    assert tail.any()
+    w[tail] = float("nan")
+    w[tail & (q % 2 == 0)] = 1e30
+    bad["fb_w"] = w
+    for mode in (1, 0):
+        knobs.set("MRMT3_LOGMEL", mode)
+        got = lib.logmel(x, bad)
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() <= (0.0 if mode == 1 else 2e-4), mode
+    knobs.set("MRMT3_LOGMEL", 1)
+    # fb_start 4 bytes off a 16-byte boundary, the window 4 bytes off an 8-byte one: the general kernel takes the call
+    off = dict(t)
+    buf = torch.zeros(t["fb_start"].numel() + 1, dtype=torch.int32, device=dev)
+    buf[1:] = t["fb_start"]
+    off["fb_start"] = buf[1:]
+    wbuf = torch.zeros(t["window"].numel() + 1, device=dev)
+    wbuf[1:] = t["window"]
+    off["window"] = wbuf[1:]
+    assert off["fb_start"].data_ptr() % 16 == 4 and off["window"].data_ptr() % 8 == 4
+    got = lib.logmel(x, off)
+    assert (got - want).abs().max().item() <= 2e-4
+
+
+def test_logmel_wave_kernel_matches_the_round1_kernel(dev, knobs):
     """Round 4's wave-per-frame kernel (64 frames per workgroup, a 16 x 16 x 4 FFT in registers, csrc/logmel.hip) against
     round 1's workgroup-per-frame kernel (MRMT3_LOGMEL=0): two independent implementations of the same transform
     (contrib/spectrograms.py:128-145) agree to f32 FFT rounding on ragged lengths, frame counts off the 64-frame grid,
@@ -78,9 +115,9 @@ def test_logmel_wave_kernel_matches_the_round1_kernel(dev, monkeypatch):
         x = torch.from_numpy((rs.uniform(-1, 1, size=(B, n)) * rs.uniform(0.01, 1.0, size=(B, 1))).astype(np.float32)).to(dev)
         vf = torch.tensor([max(1, (n // 128) // (b + 2)) for b in range(B)], dtype=torch.int32, device=dev)
         for kw in (dict(), dict(valid_frames=vf), dict(normalize=False), dict(out_bf16=True)):
-            monkeypatch.setenv("MRMT3_LOGMEL", "0")
+            knobs.set("MRMT3_LOGMEL", "0")
             old = sp.logmel_segments(x, **kw).float()
-            monkeypatch.setenv("MRMT3_LOGMEL", "1")
+            knobs.set("MRMT3_LOGMEL", "1")
             new = sp.logmel_segments(x, **kw).float()
             assert new.shape == old.shape
             tol = 4e-3 if kw.get("out_bf16") else (2e-4 if kw.get("normalize", True) else 3e-3)
@@ -98,9 +135,9 @@ def test_logmel_wave_kernel_matches_the_round1_kernel(dev, monkeypatch):
     song = torch.from_numpy(rs.uniform(-1, 1, size=128 * 700 + 77).astype(np.float32)).to(dev)
     starts = torch.tensor([0, 13, 255, 600], dtype=torch.int64)
     vfc = torch.tensor([256, 200, 256, 64], dtype=torch.int32)
-    monkeypatch.setenv("MRMT3_LOGMEL", "0")
+    knobs.set("MRMT3_LOGMEL", "0")
     old = sp.logmel_crops(song, starts, 256, valid_frames=vfc)
-    monkeypatch.setenv("MRMT3_LOGMEL", "1")
+    knobs.set("MRMT3_LOGMEL", "1")
     new = sp.logmel_crops(song, starts, 256, valid_frames=vfc)
     assert (new - old).abs().max().item() <= 2e-4
     assert (new[1, 200:] == 0).all() and (new[3, 64:] == 0).all()
@@ -382,10 +419,10 @@ ATTN_SHAPES = [(2, 6, 256, 256, False), (2, 6, 1024, 1024, True), (1, 6, 1024, 3
 
 
 @pytest.fixture(params=["coarse", "fine"])
-def tile_rows(request, monkeypatch):
+def tile_rows(request, knobs):
     """128-row tiles (32 rows per wave) or the 64-row tiles small launches take (attn_fine, csrc/attn_common.h): every
     attention shape below runs both instantiations (paired causal launches are coarse either way)."""
-    monkeypatch.setenv("MRMT3_ATTN_FINE", "1" if request.param == "fine" else "0")
+    knobs.set("MRMT3_ATTN_FINE", "1" if request.param == "fine" else "0")
     return request.param
 
 
@@ -434,7 +471,7 @@ def test_attn_bwd_bf16(dev, tile_rows, B, H, Lq, Lk, causal):
 
 
 @pytest.mark.parametrize("B,H,Lq,p", [(2, 6, 1024, 0.0), (2, 6, 256, 0.1), (1, 3, 1000, 0.1), (3, 2, 45, 0.0)])
-def test_attn_bwd_onepass_matches_autograd_and_the_two_pass_kernels(dev, monkeypatch, B, H, Lq, p):
+def test_attn_bwd_onepass_matches_autograd_and_the_two_pass_kernels(dev, knobs, B, H, Lq, p):
     """The one-pass backward (attention_onepass.hip: 256 keys, not causal — the decoder's cross-attention and the
     encoder's self-attention) against f32 autograd of the same dropped attention, and against the two-pass kernels on
     the same inputs (same masks, same bf16 operand roundings: only summation orders differ)."""
@@ -448,8 +485,8 @@ def test_attn_bwd_onepass_matches_autograd_and_the_two_pass_kernels(dev, monkeyp
     o, lse, o_lo = lib.attn_fwd(q, k, v, B, H, Lq, Lk, False, p=p, seed=31, stream_id=4, want_lo=True)
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("MRMT3_ATTN_ONEPASS", mode)
-        monkeypatch.setenv("MRMT3_ATTN_ONEPASS_MIN_BH", "1")
+        knobs.set("MRMT3_ATTN_ONEPASS", mode)
+        knobs.set("MRMT3_ATTN_ONEPASS_MIN_BH", "1")
         dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
         before = lib.dispatch_counts()
         lib.attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, Lq, Lk, False, p=p, seed=31, stream_id=4, o_lo=o_lo)
@@ -1016,7 +1053,7 @@ def test_gemm_tn_deferred_batch_is_bitwise_the_immediate_form(dev):
     # 12 segments per GPU (the reference's own batch): 12288 decoder rows, 3072 encoder rows, less than one wave of tiles
     (3072, 512, 1024, "bf16", False), (3072, 2048, 512, "bf16", False), (12288, 384, 512, "bf16", False),
     (12288, 512, 1536, "f32", False), (2048 + 72, 512, 384, "bf16", False)])
-def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypatch, M, N, K, out, acc):
+def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, knobs, M, N, K, out, acc):
     """csrc/gemm8.hip (ping-pong phases, LDS-DMA two K steps ahead, epilogue spread over four phases with counted
     waits) on every admissible shape class: against an f32 torch product on ALL rows, and against gemm.hip's kernel
     (same MFMA, same k order: expected bit-identical for f32 output)."""
@@ -1028,8 +1065,8 @@ def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypa
     base = torch.randn(M, N, device=dev).to(dt) if acc else torch.zeros(M, N, device=dev, dtype=dt)
     res = {}
     for which in ("0", "1"):
-        monkeypatch.setenv("MRMT3_GEMM8", which)
-        monkeypatch.setenv("MRMT3_GEMM8_ALL", "1")
+        knobs.set("MRMT3_GEMM8", which)
+        knobs.set("MRMT3_GEMM8_ALL", "1")
         c = base.clone()
         for _ in range(2 if acc else 1):
             lib.gemm_nt(a, b, out=c, accumulate=acc)
@@ -1044,7 +1081,7 @@ def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypa
     else:
         assert (res["0"].float() - res["1"].float()).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
     # operands and output as column slices of wider buffers (q | k | v views of the fused projection)
-    monkeypatch.setenv("MRMT3_GEMM8", "1")
+    knobs.set("MRMT3_GEMM8", "1")
     wide_a = torch.randn(M, K + 128, device=dev).bfloat16()
     wide_c = torch.zeros(M, N + 256, device=dev, dtype=dt)
     lib.gemm_nt(wide_a[:, 128:], b, out=wide_c[:, 256:])
@@ -1053,13 +1090,13 @@ def test_gemm_nt8_pingpong_kernel_against_f32_and_the_first_kernel(dev, monkeypa
     assert wide_c[:, :256].abs().max().item() == 0
 
 
-def test_gemm8_dispatch_rule_takes_whole_waves_of_tiles(dev, monkeypatch):
+def test_gemm8_dispatch_rule_takes_whole_waves_of_tiles(dev, knobs):
     """Which NT shapes go to the ping-pong kernel by default (no tuning switches): at most one wave of workgroups, or a
     last wave >= 80 % full; never the accumulate form.  (Cold A/B: profiles/r03_gemm_ab_*cold.txt.)"""
     from mrmt3 import lib
-    monkeypatch.delenv("MRMT3_GEMM8_ALL", raising=False)
-    monkeypatch.delenv("MRMT3_GEMM8", raising=False)
-    monkeypatch.delenv("MRMT3_GEMM8_MIN_M", raising=False)
+    knobs.unset("MRMT3_GEMM8_ALL")
+    knobs.unset("MRMT3_GEMM8")
+    knobs.unset("MRMT3_GEMM8_MIN_M")
     cases = [(65536, 1152, 512, True), (65536, 384, 512, True), (16384, 1152, 512, False), (12288, 512, 384, True),
              (12288, 1024, 512, False), (12288, 1536, 512, False), (3072, 512, 2048, True), (3072, 1152, 512, True),
              (1024, 512, 512, False), (65536, 512, 1024, True)]
@@ -1082,14 +1119,14 @@ def test_gemm8_dispatch_rule_takes_whole_waves_of_tiles(dev, monkeypatch):
     assert lib.dispatch_counts()["gemm_nt8"] == before
 
 
-def test_gemm8_and_tn8_race_screen_bitwise_repeatable_under_load(dev, monkeypatch):
+def test_gemm8_and_tn8_race_screen_bitwise_repeatable_under_load(dev, knobs):
     """The ping-pong kernels order every LDS hand-off by counted vmcnt + barriers (no fences): a misplaced wait shows up
     as rare wrong tiles that come and go with timing.  Screen: 150 back-to-back launches per shape, alternating with a
     bandwidth-heavy kernel (different timing every time), every result bit-identical to the first and equal to an f32
     reference."""
     from mrmt3 import lib
-    monkeypatch.setenv("MRMT3_GEMM8_ALL", "1")
-    monkeypatch.setenv("MRMT3_TN8_ALL", "1")
+    knobs.set("MRMT3_GEMM8_ALL", "1")
+    knobs.set("MRMT3_TN8_ALL", "1")
     torch.manual_seed(3)
     noise = torch.empty(64 << 20, device=dev)
     for M, N, K in ((16384, 512, 384), (65536, 1152, 512), (32768, 2048, 128)):
@@ -1151,7 +1188,7 @@ def test_lmhead_ce_fused_chunks_equal_gemm_then_ce(dev, weighted):
 
 
 @pytest.mark.gpu
-def test_gemm_nt_geglu_fused_equals_the_two_kernels_bitwise(dev, monkeypatch):
+def test_gemm_nt_geglu_fused_equals_the_two_kernels_bitwise(dev, knobs):
     """K2 + K7 in one launch (the wi projection with the gated GELU and its dropout in the GEMM epilogue): h and g are
     bit-identical to mrmt3_gemm_nt followed by mrmt3_geglu_fwd — same bf16 rounding of h before the activation, same
     counter-based mask (keyed on the flat index of g, salted by the device step) — on 256- and 128-row tiles, ragged
@@ -1165,12 +1202,12 @@ def test_gemm_nt_geglu_fused_equals_the_two_kernels_bitwise(dev, monkeypatch):
         x = torch.randn(rows, K, device=dev).bfloat16()
         wi = (torch.randn(2 * dff, K, device=dev) * 0.06).bfloat16()
         for p in (0.0, 0.1):
-            monkeypatch.setenv("MRMT3_GEGLU_FUSED", "0")
+            knobs.set("MRMT3_GEGLU_FUSED", "0")
             h0, g0 = lib.gemm_nt_geglu(x, wi, p=p, seed=1234, stream_id=5, step=step if p else None)
             h1 = lib.gemm_nt(x, wi)
             g1 = lib.geglu_fwd(h1, p=p, seed=1234, stream_id=5, step=step if p else None)
             assert torch.equal(h0, h1) and torch.equal(g0, g1)
-            monkeypatch.setenv("MRMT3_GEGLU_FUSED", "1")
+            knobs.set("MRMT3_GEGLU_FUSED", "1")
             h, g = lib.gemm_nt_geglu(x, wi, p=p, seed=1234, stream_id=5, step=step if p else None)
             assert torch.equal(h, h0), (rows, dff, K, p, (h.float() - h0.float()).abs().max().item())
             assert torch.equal(g, g0), (rows, dff, K, p, (g.float() - g0.float()).abs().max().item())
@@ -1193,7 +1230,7 @@ def test_gemm_nt_geglu_fused_equals_the_two_kernels_bitwise(dev, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_grouped_weight_gradients_match_f32_and_are_bitwise_repeatable(dev, monkeypatch):
+def test_grouped_weight_gradients_match_f32_and_are_bitwise_repeatable(dev, knobs):
     """mrmt3_tn_group_plan / _run: several weight gradients dW = dY^T X in one MFMA launch + one reduce.  Every shape of
     the training step (ragged 384 / 768 / 1152 with their shifted last tiles, strided operand views, a token count that
     is not a multiple of 128), mixed token counts in one group, accumulate on and off; against an f32 matmul of the same
@@ -1205,7 +1242,7 @@ def test_grouped_weight_gradients_match_f32_and_are_bitwise_repeatable(dev, monk
               (65536, 1152, 512), (16384 + 72, 512, 512), (4096, 1536, 512), (1024, 256, 256)]
     for n_ctas in (None, "24"):           # the real chip, and a small grid (many rounds per workgroup)
         if n_ctas:
-            monkeypatch.setenv("MRMT3_TN_GROUP_CTAS", n_ctas)
+            knobs.set("MRMT3_TN_GROUP_CTAS", n_ctas)
             shapes = shapes[4:]
         grp = lib.TnGroup()
         sites = []

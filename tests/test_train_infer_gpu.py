@@ -1,4 +1,6 @@
 """End-to-end checks of the MI355X trainer and inference harness on a real GPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -440,7 +442,7 @@ def test_bf16_training_trajectory_tracks_the_fp32_oracle(dev, variant):
     print(variant, "worst 1 - cos(update):", worst)
 
 
-def test_step_gradients_do_not_depend_on_the_launch_structure(dev, monkeypatch):
+def test_step_gradients_do_not_depend_on_the_launch_structure(dev, knobs):
     """One backward, three ways of launching it: (a) the default (weight gradients grouped into one launch, wi projection
     fused with the gated GELU, cross k|v of all layers from one projection), (b) the wi projection and the GELU as two
     kernels — bit-identical by construction, so the whole gradient must be — and (c) one launch per weight gradient —
@@ -452,13 +454,13 @@ def test_step_gradients_do_not_depend_on_the_launch_structure(dev, monkeypatch):
 
     def grads(**env):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knobs.set(k, v)
         m = _model("t5", dev, dropout_rate=0.1)
         tr = Trainer(m, lr=0.0, graph=False)
         loss = tr.train_step(mel, lab).item()
         torch.cuda.synchronize()
         for k in env:
-            monkeypatch.delenv(k)
+            knobs.unset(k)
         return loss, m.flat.G.clone(), tr
 
     l0, g0, tr0 = grads()
@@ -470,3 +472,30 @@ def test_step_gradients_do_not_depend_on_the_launch_structure(dev, monkeypatch):
     rel = ((g0 - g2).norm() / g2.norm()).item()
     assert abs(l0 - l2) < 2e-6 and rel < 2e-6, rel
     assert (g0 - g2).abs().max().item() < 1e-5 * g2.abs().max().item() + 1e-7
+
+
+def test_bench_spawns_its_ranks_through_the_launcher(dev):
+    """`bench.py --gpus N` without a launcher around it runs `torch.distributed.run` as a child and forwards rank 0's line
+    (tests/test_bench_launch_cpu.py holds the plumbing); here the real launcher on the one GPU of this box (`--spawn`: the
+    N > 1 path at N = 1), with the gradient buckets really going through RCCL (forced collectives) — the line reports what
+    the communicator saw, not the flag.  The reference's ranks: config/config.yaml:45-46, train.sh:6."""
+    import json
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MRMT3_DDP_FORCE_COLLECTIVES"] = "1"
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--batch", "4", "--steps", "3",
+                        "--warmup", "1", "--extra-batch", "0", "--no-inference", "--no-cpu-baseline", "--no-roofline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["launched_by"].startswith("bench.py --gpus 1 -> child")
+    assert d["collectives"].startswith("rccl") and d["value"] > 0 and d["steps"] == 3
+    # more ranks than GPUs on this box: refused, nothing on stdout
+    n = torch.cuda.device_count()
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode == 2 and r.stdout == "" and "visible" in r.stderr
