@@ -51,6 +51,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="segments per GPU per step")
     ap.add_argument("--variant", default="t5", choices=["t5", "segmem_v2", "segmem_v2_with_prev"])
+    ap.add_argument("--mel-frames", type=int, default=256, help="mel frames per segment (2048: BASELINE configs[4])")
     ap.add_argument("--decode-tokens", type=int, default=1024)
     ap.add_argument("--decode-batch", type=int, default=8)
     ap.add_argument("--no-inference", action="store_true")
@@ -418,7 +419,10 @@ def main():
     B = args.batch
     model = build_model(args.variant, dev)
     trainer = Trainer(model, lr=2e-4, lr_lambda=cosine_warmup_lambda(64500, 1289 * 800, min_lr=1e-4))
-    audio = torch.from_numpy(synth_audio(B, seed=365 + rank)).to(dev)
+    n_samples = args.mel_frames * 128
+    flop_per_seg = ({"t5": FLOP_PER_SEG_FWD_BWD}.get(args.variant, FLOP_PER_SEG_MRMT3) if args.mel_frames == 256 else
+                    FLOP_PER_SEG_LONG if (args.mel_frames == 2048 and args.variant == "segmem_v2_with_prev") else None)
+    audio = torch.from_numpy(synth_audio(B, n_samples, seed=365 + rank)).to(dev)
     labels = torch.from_numpy(synth_labels(B, seed=365 + rank)).to(dev)
     prev = torch.from_numpy(synth_labels(B, seed=1365 + rank)).to(dev) if args.variant == "segmem_v2_with_prev" else None
 
@@ -445,6 +449,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    trainer.check_exchange()                       # (two-graph form: no hand-off between the graphs ever timed out)
     seg_per_s = world * B * args.steps / dt
 
     res = {
@@ -455,14 +460,20 @@ def main():
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %s bf16, %d segments/GPU/step of 32768 samples @16kHz -> 256x512 mel, "
-                               "1024-token targets, dropout 0.1 on, golden-recipe weights" % (args.variant, B),
+        "config": {"workload": "BASELINE configs[%s]: %s bf16, %d segments/GPU/step of %d samples @16kHz -> %dx512 mel, "
+                               "1024-token targets, dropout 0.1 on, golden-recipe weights"
+                               % ("1" if args.variant == "t5" else "4" if args.mel_frames == 2048 else "2", args.variant, B,
+                                  n_samples, args.mel_frames),
                    "segments_per_gpu": B, "global_segments": B * world, "parallelism": "dp%d" % world,
-                   "audio_seconds_per_step": B * world * SEG_SECONDS},
+                   "audio_seconds_per_step": B * world * n_samples / 16000.0},
         "final_loss": final_loss,
         "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
         "step_graph": bool(trainer.use_graph and trainer.graph_captured),
-        "graph_segments": (len(next(iter(trainer._graphs.values())).segments) + 1) if trainer._graphs else 0,
+        # graphs replayed per step: the compute step (one per gradient bucket when collectives run eagerly between
+        # them) + AdamW's tail, + 1 when the collectives are a graph of their own (MRMT3_DDP_GRAPH=1)
+        "graph_segments": ((lambda c: len(c.segments) + 1 + (1 if c.comm is not None else 0))(next(iter(trainer._graphs.values())))
+                           if trainer._graphs else 0),
+        "collectives_captured": (trainer.ddp_graph or "no") if trainer.buckets.active else None,
         "collectives": ("rccl%s, %d buckets per step%s" % (" through the C ABI (mrmt3_allreduce)" if trainer.buckets.native else " through torch.distributed",
                                                            len(trainer.buckets.buckets), " (forced at world 1)" if force_coll and world == 1 else "")
                         if trainer.buckets.active else "none (world 1)"),
@@ -471,7 +482,7 @@ def main():
                                    {"items": int(g.last_info.n_items), "gradient_tiles": int(g.last_info.n_rtiles),
                                     "items_per_workgroup_max": int(g.last_info.rounds), "workgroups": int(g.last_info.n_ctas),
                                     "partial_tile_bytes": int(g.last_info.slab_bytes)})(trainer.engine.tn_group),
-        "model_tflops": seg_per_s * FLOP_PER_SEG_FWD_BWD / 1e12 / world,
+        "model_tflops": None if flop_per_seg is None else seg_per_s * flop_per_seg / 1e12 / world,
         "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
     if rank == 0 and world == 1 and args.extra_batch > 0:
@@ -489,7 +500,7 @@ def main():
         dtx = time.perf_counter() - t1
         res["train_b%d" % Bx] = {"segments_per_gpu": Bx, "ms_per_step": 1e3 * dtx / args.steps,
                                  "segments_per_s": Bx * args.steps / dtx,
-                                 "model_tflops": Bx * args.steps / dtx * FLOP_PER_SEG_FWD_BWD / 1e12}
+                                 "model_tflops": None if flop_per_seg is None else Bx * args.steps / dtx * flop_per_seg / 1e12}
     if not args.no_roofline:
         # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings.
         # The replayed graph is ONE chain of kernels (the grouped weight-gradient launch included), so the eager repeat
@@ -539,8 +550,9 @@ def main():
         # HBM side of the whole step: bytes per step from the committed whole-step PMC table (profiles/tools/
         # pmc_step_traffic.sh) over this run's step time, next to the MFMA fraction (the step holds 14.4 TFLOP)
         step_s = dt / args.steps
-        res["roofline"]["step"] = {"mfma_TFLOPs": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12,
-                                   "mfma_frac": B * FLOP_PER_SEG_FWD_BWD / step_s / 1e12 / PEAK_BF16_TFLOPS}
+        fps = flop_per_seg or 0.0
+        res["roofline"]["step"] = {"mfma_TFLOPs": B * fps / step_s / 1e12,
+                                   "mfma_frac": B * fps / step_s / 1e12 / PEAK_BF16_TFLOPS}
         if tab is not None:
             res["roofline"]["step"].update({"step_bytes": tab["step_bytes"], "hbm_GBps": tab["step_bytes"] / step_s / 1e9,
                                             "hbm_frac": tab["step_bytes"] / step_s / 1e9 / PEAK_HBM_GBS, "source": tab_name})
@@ -559,6 +571,7 @@ def main():
         res["train_long_context"] = timed_workload(dev, "segmem_v2_with_prev", 12, 2048 * 128, args.steps, FLOP_PER_SEG_LONG,
                                                    lr=1e-5)
     sync()
+    trainer.buckets.close()                        # the library's own communicator, if one was made (MRMT3_DDP_NATIVE / _GRAPH)
     if rank == 0 and not args.no_inference:
         del trainer, model
         torch.cuda.empty_cache()

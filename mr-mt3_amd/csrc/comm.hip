@@ -141,13 +141,18 @@ __global__ void flag_wait_kernel(const int* flag, int* seen, int* err, unsigned 
   if (threadIdx.x != 0) return;
   const int want = *seen + 1;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();                  // 100 MHz
-  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-    __builtin_amdgcn_s_sleep(64);
+  // The poll is a RELAXED device-scope load: an acquire at this scope is an L2 invalidate of the XCD the wave sits on, and
+  // one of those every microsecond through a whole backward pass cost the compute graph beside it 4 ms of a 24.7 ms step
+  // (profiles/r05_collectives_ab.txt).  One acquire fence once the signal has been seen orders what follows.
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
     if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
       __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   *seen = want;
 }
 

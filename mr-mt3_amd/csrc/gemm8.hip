@@ -314,7 +314,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(G8Params P) {
 #pragma unroll
       for (int ii = 0; ii < RH / 2; ++ii) {
         const int i = i0 + ii;
-        const int row = m0 + g * GROUP_ROWS + i * 16 + fr;
+        // (the lane's row base goes through an opaque move: hipcc otherwise keeps `base | 16 i` for every i in a register of
+        // its own from the prologue on — at 256 VGPRs those were the values it spilled and reloaded behind a vmcnt(0) in
+        // every tile's epilogue)
+        int rbase = g * GROUP_ROWS + fr;
+        asm volatile("" : "+v"(rbase));
+        const int row = m0 + rbase + i * 16;
         const unsigned h0p[4] = {pack_bf2(acc[i][0][0], acc[i][0][1]), pack_bf2(acc[i][0][2], acc[i][0][3]),
                                  pack_bf2(acc[i][1][0], acc[i][1][1]), pack_bf2(acc[i][1][2], acc[i][1][3])};
         const unsigned h1p[4] = {pack_bf2(acc[i][2][0], acc[i][2][1]), pack_bf2(acc[i][2][2], acc[i][2][3]),

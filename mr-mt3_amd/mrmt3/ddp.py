@@ -188,7 +188,12 @@ class GradBuckets:
 
     def _launch_stream(self, device):
         if self._launch is None or self._launch.device != device:
-            self._launch = torch.cuda.Stream(device=device)
+            # HIGH priority: (a) a finished bucket's collective should start at once, not behind the backward kernels that
+            # are already queued; (b) HIP multiplexes the streams of ONE priority onto a few hardware queues
+            # (GPU_MAX_HW_QUEUES = 4): at normal priority this stream can end up on the compute stream's queue, and the
+            # captured form's spinning hand-off waits (trainer.py, MRMT3_DDP_GRAPH=1) then block the very kernels they wait
+            # for — measured, profiles/r05_two_graph_probe.txt.  A high-priority stream draws from a queue pool of its own.
+            self._launch = torch.cuda.Stream(device=device, priority=int(os.environ.get("MRMT3_DDP_STREAM_PRIO", "-1")))
         return self._launch
 
     def close(self):

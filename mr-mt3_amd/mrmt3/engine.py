@@ -186,8 +186,10 @@ class Engine:
     def _proj_norm_bwd(self, a, wt, dres, x1, rstd, w_norm, dw, **kw):
         """_norm_bwd(gemm_nt(a, wt), dres, ...): the data gradient of a sublayer's input projection and the backward of the
         norm in front of it, one fused launch when the shape allows."""
-        if ((self.fuse_rows & 2) and self.y_dtype == torch.bfloat16 and dres is not None and x1.shape[1] == 512 and
-                a.shape[1] <= self.fuse_normbwd_max_k and lib.gemm_rows_ok(a, wt)):
+        # (only with the batched norm-weight reduce: without it the fused call would have to build its one-site reduce table
+        # by a host-to-device copy, which the capture of the step does not allow — ADVICE r4)
+        if ((self.fuse_rows & 2) and self.norm_dw is not None and self.y_dtype == torch.bfloat16 and dres is not None and
+                x1.shape[1] == 512 and a.shape[1] <= self.fuse_normbwd_max_k and lib.gemm_rows_ok(a, wt)):
             return lib.gemm_nt_normbwd(a, wt, dres, x1, rstd, w_norm, dw, defer=self.norm_dw, **kw)
         dxn = lib.gemm_nt(a, wt, out_dtype=self.y_dtype)
         return self._norm_bwd(dxn, dres, x1, rstd, w_norm, dw, **kw)

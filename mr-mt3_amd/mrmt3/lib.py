@@ -138,7 +138,7 @@ def load():
 MIN_VERSION = 108
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
-                 "gemm_nt_geglubwd")
+                 "gemm_nt_geglubwd", "attn_fwd_resident")
 
 
 def set_knob(name: str, value: int):
@@ -779,12 +779,25 @@ def gemm_nt_normbwd(a, wt, dres, x1, rstd, w_norm, dw, want_dy=True, p=0.0, seed
                                        _p(rstd), _p(w_norm), _p(dx1), _dt(dx1), _p(dy), p, seed, _p(step), stream_y,
                                        _p(ws), ws.numel() if ws is not None else 0, _stream()), "gemm_nt_normbwd")
     if reduce_now is not None:
-        dev = a.device
-        tab = (torch.tensor([ws.data_ptr()], dtype=torch.int64, device=dev),
-               torch.tensor([dw.data_ptr()], dtype=torch.int64, device=dev),
-               torch.tensor([n_part], dtype=torch.int32, device=dev))
+        # the one-site address table of the reduce, cached per (workspace, dw, partial rows): built by a synchronous
+        # host-to-device copy, which a hipGraph capture of the step does not allow — the eager warm-up steps leave it here
+        key = (ws.data_ptr(), dw.data_ptr(), n_part, a.device.index)
+        tab = _NORMBWD_TABLES.get(key)
+        if tab is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("gemm_nt_normbwd: the norm-weight reduce table of this site was not prepared before the "
+                                   "capture (run the step eagerly once with the same buffers, or pass defer=NormDwBatch)")
+            dev = a.device
+            tab = _NORMBWD_TABLES[key] = (torch.tensor([ws.data_ptr()], dtype=torch.int64, device=dev),
+                                          torch.tensor([dw.data_ptr()], dtype=torch.int64, device=dev),
+                                          torch.tensor([n_part], dtype=torch.int32, device=dev))
+            if len(_NORMBWD_TABLES) > 256:
+                _NORMBWD_TABLES.pop(next(iter(_NORMBWD_TABLES)))
         _check(L.mrmt3_norm_dw_reduce(_p(tab[0]), _p(tab[1]), _p(tab[2]), 1, 512, _stream()), "norm_dw_reduce")
     return dx1, dy
+
+
+_NORMBWD_TABLES = {}
 
 
 def gemm_nt_geglubwd(dy, wt, h, p=0.0, seed=0, stream_id=0, step=None):
@@ -943,6 +956,22 @@ class Comm:
         self._h = vp()
         buf = C.create_string_buffer(uid, COMM_ID_BYTES)
         _check(load().mrmt3_comm_create(buf, rank, world, C.byref(self._h)), "comm_create")
+        # a communicator nobody closed is still destroyed (ncclCommDestroy) when the object goes away or the interpreter
+        # exits — before torch's own process group is torn down at exit
+        import weakref
+        self._fin = weakref.finalize(self, Comm._destroy, self._h)
+
+    @staticmethod
+    def _destroy(h):
+        if h:
+            load().mrmt3_comm_destroy(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     @staticmethod
     def unique_id() -> bytes:
@@ -961,6 +990,7 @@ class Comm:
     def close(self):
         if self._h:
             h, self._h = self._h, vp()
+            self._fin.detach()
             _check(load().mrmt3_comm_destroy(h), "comm_destroy")
 
 

@@ -141,6 +141,17 @@ def bench_shape_inputs(batch: int = 16, length: int = 1024, seed: int = 4242):
     return mel, lab, prev
 
 
+def long_shape_inputs(batch: int = 2, frames: int = 2048, length: int = 1024, seed: int = 5151):
+    """Inputs of the long-context parity test (BASELINE configs[4], config_slakh_segmem_finetune.yaml with mel_length 2048):
+    `batch` segments of `frames` mel frames, 1024-token targets — row 0 full length, the others Slakh-shaped (EOS, then
+    -100 padding) — and an independent targets_prev stream."""
+    mel = synth_mel(batch * (frames // 256), seed=seed).reshape(batch, frames, 512)
+    lab = synth_labels(batch, length, seed=seed + 1, full=False, mean_len=500)
+    lab[0] = synth_labels(batch, length, seed=seed + 2, full=True)[0]
+    prev = synth_labels(batch, length, seed=seed + 3, full=False, mean_len=500)
+    return mel, lab, prev
+
+
 def sinusoid_table(n_pos: int, dim: int):
     """`FixedPositionalEmbedding`, reference `models/t5.py:705-719`: [sin | cos] halves (not
     interleaved).  Computed with torch CPU fp32 ops in the reference's own op order so the table

@@ -233,6 +233,18 @@ class Trainer:
                               timeout_ms=int(os.environ.get("MRMT3_DDP_GRAPH_TIMEOUT_MS", "20000")))
         return self._hand
 
+    def _side_by_side(self, compute_stream, collective_stream) -> bool:
+        """Do kernels of the two streams run side by side?  A spinning wait on the collective stream, then its signal on
+        the compute stream: if the wait times out, both streams feed ONE hardware queue (HIP shares a few queues among
+        the streams of a priority) and the two-graph form must not be used.  Eager, once per capture, 0.1 ms when fine."""
+        dev = self.flat.G.device
+        w = torch.zeros(3, dtype=torch.int32, device=dev)            # flag, seen, err
+        torch.cuda.synchronize()
+        lib.flag_wait(w[0:1], w[1:2], w[2:3], 250, stream=collective_stream)
+        lib.flag_signal(w[0:1], stream=compute_stream)
+        torch.cuda.synchronize()
+        return int(w[2].item()) == 0
+
     def check_exchange(self):
         """Raises if a hand-off between the compute graph and the collective graph ever timed out (host sync: call it where
         the host waits anyway — end of an epoch, a checkpoint, the end of a benchmark)."""
@@ -281,6 +293,9 @@ class Trainer:
             eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
         mode = self.ddp_graph if self.buckets.active else ""
         before_opt, order = None, []
+        if mode and mode != "inline" and not self._side_by_side(cur, self.buckets.collective_stream(cap.inputs.device)):
+            raise RuntimeError("the compute stream and the collective stream share a hardware queue: two graphs with "
+                               "spinning hand-offs between them would block each other")
         if mode:
             comm = self.buckets.comm()         # created (and used by the eager steps) before anything captures
             G = self.flat.G

@@ -70,15 +70,37 @@ def real_loaders(cfg, world=1, rank=0):
             "to run synthetic Slakh-shaped batches.") from e
     kw_t = {k: v for k, v in dict(cfg.dataloader.train).items()}
     kw_v = {k: v for k, v in dict(cfg.dataloader.val).items()}
-    sampler = None
+    from torch.utils.data.distributed import DistributedSampler
+    # The training order is a function of (seed, epoch) at EVERY world size — one rank included, where a plain
+    # shuffle=True would draw its permutation from the global RNG and a resumed epoch would come in another order than
+    # the interrupted one (samples seen twice, others never: ADVICE r4).  The batches are cut by a sampler that can drop
+    # its first k batches at the index level: a resumed epoch does not decode and collate what it then throws away.
+    sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=bool(kw_t.pop("shuffle", False)),
+                                 seed=int(cfg.seed))
+    batches = SkippingBatchSampler(sampler, int(kw_t.pop("batch_size", 1)), bool(kw_t.pop("drop_last", False)))
     if world > 1:
-        from torch.utils.data.distributed import DistributedSampler
-        sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=bool(kw_t.pop("shuffle", False)),
-                                     seed=int(cfg.seed))
-        kw_t["sampler"] = sampler
         kw_v.pop("shuffle", None)
         kw_v["sampler"] = DistributedSampler(val_set, num_replicas=world, rank=rank, shuffle=False)
-    return (DataLoader(train_set, collate_fn=collate, **kw_t), DataLoader(val_set, collate_fn=collate, **kw_v), sampler)
+    return (DataLoader(train_set, collate_fn=collate, batch_sampler=batches, **kw_t),
+            DataLoader(val_set, collate_fn=collate, **kw_v), sampler if world > 1 else None)
+
+
+class SkippingBatchSampler(torch.utils.data.BatchSampler):
+    """torch's BatchSampler whose NEXT pass drops its first `skip` batches (index lists, nothing loaded); `len()` stays the
+    full epoch (it is the steps-per-epoch of the resume arithmetic).  `set_epoch` goes through to the sampler."""
+
+    def __init__(self, sampler, batch_size, drop_last):
+        super().__init__(sampler, batch_size, drop_last)
+        self.skip = 0
+
+    def set_epoch(self, epoch):
+        if hasattr(self.sampler, "set_epoch"):
+            self.sampler.set_epoch(epoch)
+
+    def __iter__(self):
+        import itertools
+        skip, self.skip = self.skip, 0
+        return itertools.islice(super().__iter__(), skip, None)
 
 
 def resume_position(global_step, steps_per_epoch):
@@ -95,12 +117,17 @@ def loader_batches(loader, device, epochs, max_steps, start_epoch=0, start_step=
     run continues at (start_epoch, start_step) and drops the first `skip` batches of that epoch (the ones the
     interrupted run consumed): `max_steps` counts global steps, like Lightning's."""
     n = start_step
+    bs = getattr(loader, "batch_sampler", None)
+    index_skip = isinstance(bs, SkippingBatchSampler)
     for ep in range(start_epoch, epochs):
-        if sampler is not None:
-            sampler.set_epoch(ep)            # a different shuffle per epoch, the same one on every rank
+        if index_skip:
+            bs.set_epoch(ep)                 # a different shuffle per epoch: a function of (seed, epoch), on every rank
+            bs.skip = skip if ep == start_epoch else 0
+        elif sampler is not None:
+            sampler.set_epoch(ep)
         for bi, batch in enumerate(loader):
-            if ep == start_epoch and bi < skip:
-                continue
+            if not index_skip and ep == start_epoch and bi < skip:
+                continue                     # (a loader of another kind: the consumed batches are loaded and dropped)
             if max_steps is not None and n >= max_steps:
                 return
             inputs, targets = batch[0], batch[1]
@@ -209,6 +236,8 @@ def main(argv=None):
         trainer.save_checkpoint(os.path.join(out_dir, "last.ckpt"), epoch=0 if synthetic else last_ep)
         trainer.save_checkpoint(os.path.join(out_dir, "last.pt"))
         print(f"Saved model in {os.path.join(out_dir, 'last.pt')}.", flush=True)
+    trainer.check_exchange()             # (collectives captured as a graph: no hand-off ever timed out)
+    trainer.buckets.close()              # the library's own RCCL communicator (MRMT3_DDP_NATIVE / MRMT3_DDP_GRAPH), before torch's
     if world > 1:
         dist.destroy_process_group()
     return task

@@ -143,6 +143,9 @@ def main():
                     help="only record the reference's fp32 loss / sampled logits / per-tensor gradient norms + samples, "
                          "and its autocast deviations, at B=16 x 1024 tokens (tests/golden/bench_shape.npz): the shape "
                          "at which the kernels the benchmark times dispatch")
+    ap.add_argument("--long-shape", action="store_true",
+                    help="only record the same quantities for segmem_v2_with_prev at BASELINE configs[4]'s shape — B=2 x 2048 "
+                         "mel frames (+64 memory slots) x 1024 tokens (tests/golden/long_shape.npz)")
     ap.add_argument("--v1-decode", action="store_true",
                     help="only add T5SegMem's generate / generate_2 outputs to the existing npz")
     args = ap.parse_args()
@@ -262,11 +265,11 @@ def main():
         np.savez_compressed(os.path.join(HERE, "bf16_bound.npz"), **rec)
         print("wrote bf16_bound.npz")
         return
-    if args.bench_shape:
-        from mrmt3.synthetic import bench_shape_inputs
-        mel_b, lab_b, prev_b = (torch.from_numpy(a) for a in bench_shape_inputs())
+    if args.bench_shape or args.long_shape:
+        from mrmt3.synthetic import bench_shape_inputs, long_shape_inputs
+        mel_b, lab_b, prev_b = (torch.from_numpy(a) for a in (long_shape_inputs() if args.long_shape else bench_shape_inputs()))
         rec = {}
-        for variant in ("t5", "segmem_v2_with_prev"):
+        for variant in (("segmem_v2_with_prev",) if args.long_shape else ("t5", "segmem_v2_with_prev")):
             m = build_reference(variant)
             grads, logits = {}, {}
             for mode in ("fp32", "autocast"):
@@ -309,12 +312,13 @@ def main():
             rec[f"{variant}.grad_sample_idx"] = np.stack(samp_i)
             rec[f"{variant}.grad_sample_val"] = np.stack(samp_v)
             w = int(np.argmax(rels))
-            print(variant, "autocast gradient at B=16x1024: worst rel-L2 %.3e (%s), worst cos %.5f, median rel-L2 %.3e; "
-                  "logits max|d| %.3e rel-L2 %.3e" % (rels[w], names[w], min(coss), float(np.median(rels)),
+            print(variant, "autocast gradient at B=%dx%d (%d frames): worst rel-L2 %.3e (%s), worst cos %.5f, median rel-L2 %.3e; "
+                  "logits max|d| %.3e rel-L2 %.3e" % (lab_b.shape[0], lab_b.shape[1], mel_b.shape[1], rels[w], names[w], min(coss), float(np.median(rels)),
                                                         rec[f"{variant}.autocast_max_abs"], rec[f"{variant}.autocast_rel_l2"]),
                   flush=True)
-        np.savez_compressed(os.path.join(HERE, "bench_shape.npz"), **rec)
-        print("wrote bench_shape.npz")
+        name = "long_shape.npz" if args.long_shape else "bench_shape.npz"
+        np.savez_compressed(os.path.join(HERE, name), **rec)
+        print("wrote", name)
         return
     if args.v1_decode:
         import contextlib, io

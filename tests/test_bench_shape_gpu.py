@@ -26,6 +26,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_shape.npz")
+FIX_LONG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "long_shape.npz")
 
 
 def _build(variant, dtype, dev):
@@ -39,14 +40,14 @@ def _build(variant, dtype, dev):
     return m.load_golden().to(dev).eval()
 
 
-_ORACLE = {}          # variant -> (sd with .grad, logits, loss): the CPU oracle pass is shared by the tile-height cases
+_ORACLE = {}          # (shape, variant) -> (sd with .grad, loss): the CPU oracle pass is shared by the tile-height cases
 
 
-def _oracle(variant, fix, mel, lab, prev):
+def _oracle(variant, fix, mel, lab, prev, shape="bench"):
     from mrmt3.synthetic import T5_SMALL, golden_weights
     from oracle import t5_ref
-    if variant in _ORACLE:
-        return _ORACLE[variant]
+    if (shape, variant) in _ORACLE:
+        return _ORACLE[(shape, variant)]
 
     # ---- the oracle at this shape, pinned to the reference's recorded outputs ---------------------------------
     torch.set_num_threads(min(16, os.cpu_count() or 8))
@@ -67,8 +68,8 @@ def _oracle(variant, fix, mel, lab, prev):
         assert abs(g.double().norm().item() - norm) <= 1e-4 * norm + 1e-9, n
         np.testing.assert_allclose(g.reshape(-1)[torch.from_numpy(si)].numpy(), sv, rtol=0,
                                    atol=2e-4 * float(np.abs(sv).max()) + 1e-9, err_msg=n)
-    _ORACLE[variant] = (sd, ref_loss.detach())
-    return _ORACLE[variant]
+    _ORACLE[(shape, variant)] = (sd, ref_loss.detach())
+    return _ORACLE[(shape, variant)]
 
 
 @pytest.mark.parametrize("tile", ["auto", 128], ids=["tile_auto", "tile128"])
@@ -93,7 +94,27 @@ def test_bench_shape_loss_logits_and_every_gradient_vs_oracle(variant, tile, kno
         knobs.set("MRMT3_ROWS_BM", tile)                  # the tiles the 64-segment benchmark batch takes by itself
         assert lib.load().mrmt3_gemm_nt_normbwd_partial_rows(B * Ld) == B * Ld // 128
 
-    # ---- the HIP path the benchmark times ---------------------------------------------------------------------
+    counts, eng = _hip_path_vs_oracle(variant, fix, mel, lab, prev, sd, ref_loss, "bench shape")
+    # the kernels of the benchmark step really ran: ping-pong NT, fused wi + GEGLU, grouped weight gradients
+    # (at 16 segments the dispatch rule gives the ping-pong kernel 57 of the step's NT products — both its 256-row and
+    # its 128-row form — and the others to the tile kernel; at 64 segments it is 113 of 161, same kernels)
+    assert counts["gemm_nt8"] >= 40 and counts["gemm_nt_geglu"] >= 16, counts
+    assert counts["tn_group"] >= 1 and eng.tn_group.last_info.n_items > 0, counts
+    assert counts["attn_fwd"] >= 24 and counts["attn_bwd"] + counts["attn_bwd_onepass"] >= 24, counts
+    # ... and the fused backward row kernels (MRMT3_FUSE_ROWS default 6): d_qkv / d_cq -> norm backward (8 encoder + 16
+    # decoder sites), d_wo -> gated-GELU backward (16 sites).  A silent fall-back to the two-kernel form fails here.
+    assert eng.fuse_rows & 6 == 6, eng.fuse_rows
+    assert counts["gemm_nt_normbwd"] >= 16 and counts["gemm_nt_geglubwd"] >= 16, counts
+
+
+def _hip_path_vs_oracle(variant, fix, mel, lab, prev, sd, ref_loss, what):
+    """The HIP bf16 training path (forward -> fused lm_head + CE -> backward) against the oracle's loss, the reference's
+    recorded logits and every gradient tensor of the oracle; returns (dispatch counts of that pass, engine)."""
+    from mrmt3 import lib
+    dev = torch.device("cuda:0")
+    idx = torch.from_numpy(fix[f"{variant}.logit_idx"])
+    ref_logit = fix[f"{variant}.logit_val"]
+    names = fix[f"{variant}.grad_names"].tolist()
     m = _build(variant, torch.bfloat16, dev)
     eng, flat = m.engine, m.flat
     flat.ensure_grads()
@@ -110,22 +131,12 @@ def test_bench_shape_loss_logits_and_every_gradient_vs_oracle(variant, tile, kno
     eng.backward(tape, dl)
     torch.cuda.synchronize()
     counts = lib.dispatch_counts()
-    print(variant, "dispatch:", counts, "grouped weight-gradient items:", eng.tn_group.last_info.n_items)
-    # the kernels of the benchmark step really ran: ping-pong NT, fused wi + GEGLU, grouped weight gradients
-    # (at 16 segments the dispatch rule gives the ping-pong kernel 57 of the step's NT products — both its 256-row and
-    # its 128-row form — and the others to the tile kernel; at 64 segments it is 113 of 161, same kernels)
-    assert counts["gemm_nt8"] >= 40 and counts["gemm_nt_geglu"] >= 16, counts
-    assert counts["tn_group"] >= 1 and eng.tn_group.last_info.n_items > 0, counts
-    assert counts["attn_fwd"] >= 24 and counts["attn_bwd"] + counts["attn_bwd_onepass"] >= 24, counts
-    # ... and the fused backward row kernels (MRMT3_FUSE_ROWS default 6): d_qkv / d_cq -> norm backward (8 encoder + 16
-    # decoder sites), d_wo -> gated-GELU backward (16 sites).  A silent fall-back to the two-kernel form fails here.
-    assert eng.fuse_rows & 6 == 6, eng.fuse_rows
-    assert counts["gemm_nt_normbwd"] >= 16 and counts["gemm_nt_geglubwd"] >= 16, counts
+    print(variant, what, "dispatch:", counts, "grouped weight-gradient items:", eng.tn_group.last_info.n_items)
 
     d_loss = abs(loss.item() - ref_loss.item())
     rel = np.linalg.norm(got - ref_logit) / np.linalg.norm(ref_logit)
     max_d = float(np.abs(got - ref_logit).max())
-    print(variant, "bench shape: loss %.6f oracle %.6f (|d| %.2e); logits rel-L2 %.3e max|d| %.3e (autocast: %.3e / %.3e)"
+    print(variant, what + ": loss %.6f oracle %.6f (|d| %.2e); logits rel-L2 %.3e max|d| %.3e (autocast: %.3e / %.3e)"
           % (loss.item(), ref_loss.item(), d_loss, rel, max_d, float(fix[f"{variant}.autocast_rel_l2"]),
              float(fix[f"{variant}.autocast_max_abs"])))
     assert d_loss < 1e-3                                            # north_star tolerance on the loss
@@ -149,5 +160,40 @@ def test_bench_shape_loss_logits_and_every_gradient_vs_oracle(variant, tile, kno
         ratios.append(rl / max(auto_rel[k], 1e-9))
         assert cos > 0.9995 and rl < 4e-2, (k, cos, rl)
         assert rl <= 1.5 * auto_rel[k] + 2e-3, (k, rl, auto_rel[k])
-    print(variant, "bench shape gradients: worst rel-L2 %.3e (%s), worst cosine %.6f (%s), median ratio to the "
+    print(variant, what + " gradients: worst rel-L2 %.3e (%s), worst cosine %.6f (%s), median ratio to the "
           "reference's autocast deviation %.2f, max %.2f" % (worst_rel + worst_cos + (float(np.median(ratios)), max(ratios))))
+    return counts, eng
+
+
+def test_long_context_shape_loss_logits_and_every_gradient_vs_oracle(knobs):
+    """BASELINE configs[4] (config_slakh_segmem_finetune.yaml, models/t5_segmem_v2_with_prev.py:60-153) at the shape a
+    segment of the 12-segment step has: 2048 mel frames + 64 memory slots, 1024-token targets, B = 2 (VERDICT r4 item 8 —
+    until now this config was held to the oracle at B = 1 x 128 tokens only).  Same three legs as the bench shape: the
+    oracle pinned to what the reference recorded at this shape (tests/golden/long_shape.npz, make_golden.py
+    --long-shape), fp32 logits of the HIP engine within 2e-4 of the reference's, the bf16 training path against the oracle
+    under the bench-shape rule — loss within 1e-3, every gradient tensor within 1.5 x the reference's own autocast
+    deviation — and the dispatch this shape takes: two-pass attention backward at 2048 / 2112 keys, the fused row kernels on
+    the encoder's 4096 rows, the grouped weight gradients."""
+    from mrmt3 import lib
+    from mrmt3.synthetic import long_shape_inputs
+    variant = "segmem_v2_with_prev"
+    fix = np.load(FIX_LONG)
+    mel, lab, prev = (torch.from_numpy(a) for a in long_shape_inputs())
+    assert tuple(mel.shape) == (2, 2048, 512) and tuple(lab.shape) == (2, 1024)
+    knobs.unset("MRMT3_ROWS_BM")
+    sd, ref_loss = _oracle(variant, fix, mel, lab, prev, shape="long")
+    # fp32 engine: logits against the reference's own
+    dev = torch.device("cuda:0")
+    m32 = _build(variant, torch.float32, dev)
+    with torch.no_grad():
+        got32 = m32(inputs=mel.to(dev), labels=lab.to(dev), targets_prev=prev.clone().to(dev))
+    idx = torch.from_numpy(fix[f"{variant}.logit_idx"])
+    np.testing.assert_allclose(got32.reshape(-1)[idx.to(dev)].cpu().numpy(), fix[f"{variant}.logit_val"], atol=2e-4, rtol=0)
+    del m32, got32
+    counts, eng = _hip_path_vs_oracle(variant, fix, mel, lab, prev, sd, ref_loss, "long context")
+    # 8 encoder self-attention sites over 2048 keys, 8 decoder cross-attention sites over 2048 + 64 keys, 8 causal sites,
+    # the memory encoder's one: all on the two-pass backward (the one-pass kernel owns exactly 256 keys)
+    assert counts["attn_bwd_onepass"] == 0 and counts["attn_bwd"] == 25 and counts["attn_fwd"] == 25, counts
+    assert counts["gemm_nt_normbwd"] == 24 and counts["gemm_nt_geglubwd"] == 16, counts
+    assert counts["tn_group"] >= 1 and eng.tn_group.last_info.n_items > 0, counts
+    assert counts["gemm_nt8"] >= 8 and counts["gemm_nt_geglu"] >= 8, counts

@@ -137,3 +137,31 @@ def test_logmel_oracle_against_an_independent_float64_dft_and_analytic_triangles
     # and the filterbank itself: same non-zero pattern and values as the restated torchaudio formula (f32)
     fb_ref = logmel_ref.melscale_fbanks().numpy()
     assert ((fb_ref > 0) == (fb > 1e-9)).mean() > 0.9999 and np.abs(fb_ref - fb).max() < 2e-4
+
+
+def test_oracle_at_the_long_context_shape_matches_what_the_reference_recorded():
+    """BASELINE configs[4] (config_slakh_segmem_finetune.yaml, mel_length 2048): the oracle's loss, sampled logits and EVERY
+    gradient tensor (norm + 256 sampled elements) at B = 2 x 2048 frames (+64 memory slots) x 1024 tokens against what the
+    reference itself produced at that shape (tests/golden/long_shape.npz, make_golden.py --long-shape) — the pin the GPU
+    test of the same name (tests/test_bench_shape_gpu.py) stands on."""
+    import os
+    from mrmt3.synthetic import long_shape_inputs
+    from conftest import GOLDEN
+    fix = np.load(os.path.join(GOLDEN, "long_shape.npz"))
+    variant = "segmem_v2_with_prev"
+    torch.set_num_threads(8)
+    mel, lab, prev = (torch.from_numpy(a) for a in long_shape_inputs())
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in golden_weights(T5_SMALL, 1).items()}
+    logits = t5_ref.forward_logits(sd, T5_SMALL, mel, lab, variant=variant, targets_prev=prev.clone())
+    loss = t5_ref.ce_loss(logits, lab)
+    loss.backward()
+    idx = torch.from_numpy(fix[f"{variant}.logit_idx"])
+    np.testing.assert_allclose(logits.detach().reshape(-1)[idx].numpy(), fix[f"{variant}.logit_val"], atol=5e-5, rtol=0)
+    assert abs(loss.item() - float(fix[f"{variant}.fp32.loss"])) < 2e-5
+    for n, norm, si, sv in zip(fix[f"{variant}.grad_names"].tolist(), fix[f"{variant}.grad_norm"],
+                               fix[f"{variant}.grad_sample_idx"], fix[f"{variant}.grad_sample_val"]):
+        g = sd[n].grad
+        assert g is not None, n
+        assert abs(g.double().norm().item() - norm) <= 1e-4 * norm + 1e-9, n
+        np.testing.assert_allclose(g.reshape(-1)[torch.from_numpy(si)].numpy(), sv, rtol=0,
+                                   atol=2e-4 * float(np.abs(sv).max()) + 1e-9, err_msg=n)

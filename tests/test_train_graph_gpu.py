@@ -284,3 +284,136 @@ def test_failed_capture_falls_back_to_a_correct_eager_step(dev):
         runs[sabotage] = (m.flat.P.clone(), m.flat.M.clone(), m.flat.V.clone())
     for a, b in zip(runs[False], runs[True]):
         assert torch.equal(a, b)
+
+
+def test_flag_handoffs_order_two_streams_and_time_out_instead_of_hanging(dev):
+    """mrmt3_flag_signal / mrmt3_flag_wait (csrc/comm.hip): a counting hand-off between two streams.  The waiting stream
+    runs behind the signalling one even though the host enqueued it FIRST; an old signal cannot satisfy a new wait; a wait
+    nobody signals raises the error word after its timeout and lets the stream go on."""
+    from mrmt3 import lib
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    seen = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(1 << 24, device=dev)
+    out = torch.zeros(3, device=dev)
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        with torch.cuda.stream(b):                   # consumer first: it must wait for the producer's fill of this round
+            lib.flag_wait(flag, seen, err, 20000, stream=b)
+            out[rnd] = x[-1]
+        with torch.cuda.stream(a):
+            for _ in range(20):                      # something that takes a while
+                x.add_(0.0)
+            x.fill_(float(rnd + 1))
+            lib.flag_signal(flag, stream=a)
+    torch.cuda.synchronize()
+    assert out.tolist() == [1.0, 2.0, 3.0] and int(flag.item()) == 3 and int(seen.item()) == 3 and int(err.item()) == 0
+    # nobody signals: the wait gives up after 50 ms, says so, and the stream continues
+    with torch.cuda.stream(b):
+        lib.flag_wait(flag, seen, err, 50, stream=b)
+        out[0] = 7.0
+    b.synchronize()
+    assert int(err.item()) == 1 and out[0].item() == 7.0 and int(seen.item()) == 4
+
+
+@pytest.mark.parametrize("mode", ["1", "inline"])
+def test_collectives_captured_in_the_step_equal_the_eager_bucketed_step(dev, monkeypatch, mode):
+    """MRMT3_DDP_GRAPH: the gradient buckets' all-reduces captured — "1": as a second graph replayed beside the compute
+    graph on the collective stream, ordered by flag hand-offs; "inline": as nodes of the compute chain.  One rank with the
+    collectives forced through the library's own RCCL communicator (every bucket really goes through mrmt3_allreduce).
+    No graph segment per bucket any more, and losses, weights and AdamW moments equal the EAGER bucketed step bit for bit
+    (DDP's overlap: config/config.yaml:45)."""
+    import socket
+    import torch.distributed as dist
+    from mrmt3.trainer import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("MRMT3_DDP_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("MRMT3_DDP_NATIVE", "1")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        data = _batches(dev, 2, B=8, L=256)
+        runs = {}
+        for captured in (False, True):
+            if captured:
+                monkeypatch.setenv("MRMT3_DDP_GRAPH", mode)
+            else:
+                monkeypatch.delenv("MRMT3_DDP_GRAPH", raising=False)
+            m = _model("t5", dev)
+            tr = Trainer(m, lr=1e-3, graph=captured, layers_per_bucket=2)
+            assert tr.buckets.active and tr.buckets.native and len(tr.buckets.buckets) >= 6
+            losses = [float(tr.train_step(*data[i % 2][:2], audio=True).item()) for i in range(7)]
+            torch.cuda.synchronize()
+            assert tr.graph_captured == captured
+            if captured:
+                cap = next(iter(tr._graphs.values()))
+                assert cap.segments == [] and (cap.comm is not None) == (mode == "1")      # one compute graph (+ one of collectives)
+                assert tr.ddp_graph == mode
+                tr.check_exchange()
+                if mode == "1":
+                    h = tr._hand
+                    n_replays = 7 - tr.graph_warmup
+                    assert h["flags"].tolist() == [n_replays] * (len(tr.buckets.buckets) + 1) == h["seen"].tolist()
+            runs[captured] = (losses, m.flat.P.clone(), m.flat.M.clone(), m.flat.V.clone())
+            tr.buckets.close()
+        assert runs[False][0] == runs[True][0]
+        for a, b in zip(runs[False][1:], runs[True][1:]):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("why", ["collective_refuses_capture", "streams_share_a_hardware_queue"])
+def test_collectives_that_do_not_capture_fall_back_to_graph_segments(dev, monkeypatch, why):
+    """"keep the segmented path as the fallback when capture of a collective fails".  Either the collective
+    is made to refuse a capturing stream, or the trainer's own check says that the compute and the collective stream do not
+    run side by side (one hardware queue for both: the spinning hand-offs would block each other,
+    profiles/r05_two_graph_probe.txt).  The trainer warns, captures one graph per bucket with eager collectives instead,
+    and its weights equal those of a trainer that never tried."""
+    import socket
+    import warnings
+    import torch.distributed as dist
+    from mrmt3 import lib
+    from mrmt3.trainer import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("MRMT3_DDP_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("MRMT3_DDP_NATIVE", "1")
+    real = lib.Comm.allreduce
+
+    def refusing(self, t, average=False, stream=None):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("allreduce: this communicator does not capture")
+        return real(self, t, average=average, stream=stream)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        data = _batches(dev, 2, B=8, L=256)
+        runs = {}
+        for sabotage in (False, True):
+            if sabotage:
+                monkeypatch.setenv("MRMT3_DDP_GRAPH", "1")
+                if why == "collective_refuses_capture":
+                    monkeypatch.setattr(lib.Comm, "allreduce", refusing)
+                else:
+                    monkeypatch.setattr(Trainer, "_side_by_side", lambda self, a, b: False)
+            m = _model("t5", dev)
+            tr = Trainer(m, lr=1e-3, graph=True, layers_per_bucket=2)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                for i in range(6):
+                    tr.train_step(*data[i % 2][:2], audio=True)
+            torch.cuda.synchronize()
+            cap = next(iter(tr._graphs.values()))
+            assert tr.graph_captured and cap.comm is None and len(cap.segments) == len(tr.buckets.buckets)
+            if sabotage:
+                assert tr.ddp_graph == "" and any("falling back to one graph per bucket" in str(x.message) for x in w)
+            runs[sabotage] = (m.flat.P.clone(), m.flat.M.clone())
+            tr.buckets.close()
+        assert torch.equal(runs[False][0], runs[True][0]) and torch.equal(runs[False][1], runs[True][1])
+    finally:
+        dist.destroy_process_group()

@@ -83,3 +83,35 @@ def test_resume_position_from_the_step_count_never_overshoots_the_schedule(tmp_p
         rest = list(train.loader_batches(tl, dev, epochs=epochs, max_steps=None, start_epoch=ep0, start_step=done, skip=skip))
         assert done + len(rest) == spe * epochs, (done, len(rest))
         assert [b[0] for b in rest] == [e for e in range(epochs) for _ in range(spe)][done:]
+
+
+def test_resumed_epoch_replays_the_interrupted_order_without_loading_the_consumed_batches(tmp_path):
+    """at ONE rank too the epoch's order is a function of (seed, epoch) — the resumed epoch continues the
+    interrupted one sample for sample — and the consumed batches are skipped at the index level: the dataset is never
+    asked for them."""
+    import train
+    cfg = _cfg(tmp_path, n_train=12)
+    dev = torch.device("cpu")
+    tl, _, _ = train.real_loaders(cfg)
+    spe = len(tl)
+    assert spe == 6
+    torch.manual_seed(1)
+    full = [[int(v) for v in y[:, 0]] for _, _, y, _ in train.loader_batches(tl, dev, epochs=3, max_steps=None)]
+    assert sorted(v for b in full[:spe] for v in b) == list(range(12))                # an epoch is a permutation ...
+    assert full[:spe] != full[spe:2 * spe]                                              # ... another one every epoch
+    torch.manual_seed(999)                                                              # (the global RNG plays no part)
+    tl2, _, _ = train.real_loaders(cfg)
+    fetched = []
+    ds = tl2.dataset
+    real_get = type(ds).__getitem__
+    type(ds).__getitem__ = lambda self, i: (fetched.append(i), real_get(self, i))[1]
+    try:
+        for done in (0, 4, 6, 8, 13):
+            del fetched[:]
+            ep0, skip = train.resume_position(done, spe)
+            rest = [[int(v) for v in y[:, 0]] for _, _, y, _ in
+                    train.loader_batches(tl2, dev, epochs=3, max_steps=None, start_epoch=ep0, start_step=done, skip=skip)]
+            assert rest == full[done:], done
+            assert sorted(fetched) == sorted(v for b in full[done:] for v in b), done   # nothing consumed earlier was loaded
+    finally:
+        type(ds).__getitem__ = real_get
