@@ -70,8 +70,7 @@ void mrmt3_host_free(void* p);
 #define MRMT3_CNT_GEMM_NT_ADDNORM 12  /* projection + residual add + RMS norm in one launch (mrmt3_gemm_nt_addnorm) */
 #define MRMT3_CNT_GEMM_NT_NORMBWD 13  /* data gradient + norm backward in one launch (mrmt3_gemm_nt_normbwd) */
 #define MRMT3_CNT_GEMM_NT_GEGLUBWD 14 /* wo data gradient + gated-GELU backward in one launch (mrmt3_gemm_nt_geglubwd) */
-#define MRMT3_CNT_ATTN_FWD_RESIDENT 15 /* of the bf16 flash forwards: those with K | V resident in LDS (<= 320 keys, csrc/attention_resident.hip) */
-#define MRMT3_CNT_N 16
+#define MRMT3_CNT_N 15
 int mrmt3_dispatch_counts(unsigned long long* out, int n, int reset);
 
 /* Dispatch / tuning switches ("knobs").  Which kernel or tile shape a call takes is a function of its arguments; a few

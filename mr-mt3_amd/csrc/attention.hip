@@ -613,12 +613,6 @@ extern "C" int mrmt3_attn_fwd(const void* q, int ldq, const void* k, int ldk, co
   P.B = B; P.H = H; P.Lq = Lq; P.Lk = Lk; P.causal = causal;
   P.drop = make_attn_drop(p_drop, seed, stream_id, step_dev);
   P.tile_mode = attn_tile_mode();
-  if (mrmt3_attn_fwd_resident_try(P, s)) {     // at most 320 keys (cross-attention): K | V resident in LDS, 256 queries per workgroup
-    MR_CHECK_LAUNCH("attn_fwd resident");
-    mrmt3_count(MRMT3_CNT_ATTN_FWD);
-    mrmt3_count(MRMT3_CNT_ATTN_FWD_RESIDENT);
-    return MRMT3_OK;
-  }
   const bool pair = attn_paired(Lq, causal, H, B);
   if (attn_fine(Lq, pair, causal, H, B)) {                          // small launch: 64-row tiles
     const dim3 gf(ceil_div(Lq, 64), H, B);

@@ -15,6 +15,10 @@
 // delta = rowsum(dO * (O + O_lo)) of the NEXT block is formed from the staged dO / O / O_lo tiles, four rows per wave.
 // 5 products, one exp and one mask per pair; the same bits in dK / dV as the two-pass kernels' arithmetic up to the
 // order of the query blocks (identical: ascending), dQ summed over keys in one chain instead of per 64-key tile.
+// (Round 5, measured and closed: the two waves of a SIMD — w and w + 4 — taking phase A and the tail (delta of the next block,
+// dQ of the previous one) in OPPOSITE order inside a barrier interval, the cheapest form of a half-block stagger: 155 -> 176-181 us
+// per cross-attention site, +0.2 ms per step, profiles/r05_onepass_stagger_ab.txt.  MFMA and VALU instructions do not overlap on
+// a gfx950 SIMD, so there is nothing for a stagger to overlap; what it adds is 20 VGPRs and a second copy of the loop.)
 #include "attn_common.h"
 
 #define OP_LK 256

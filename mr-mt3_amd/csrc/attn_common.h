@@ -197,8 +197,6 @@ __device__ __forceinline__ void blds_rows8(__amdgpu_buffer_rsrc_t r, unsigned la
 }
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// attention_resident.hip: the forward with every key of a (batch, head) resident in LDS (short key sets); 1 = launched
-int mrmt3_attn_fwd_resident_try(const AttnParams& P, hipStream_t s);
 // attention_onepass.hip: the backward in one pass when a workgroup can own all keys of a (batch, head); 1 = launched
 int mrmt3_attn_bwd_onepass_try(const AttnParams& P, hipStream_t s);
 

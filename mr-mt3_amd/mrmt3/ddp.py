@@ -186,14 +186,19 @@ class GradBuckets:
         """The stream the buckets' collectives run on (never the compute stream)."""
         return self._launch_stream(device)
 
+    def use_collective_stream(self, stream):
+        """Run the collectives on `stream` from now on (the trainer picks one that shares no hardware queue with compute)."""
+        self._launch = stream
+
     def _launch_stream(self, device):
         if self._launch is None or self._launch.device != device:
-            # HIGH priority: (a) a finished bucket's collective should start at once, not behind the backward kernels that
-            # are already queued; (b) HIP multiplexes the streams of ONE priority onto a few hardware queues
-            # (GPU_MAX_HW_QUEUES = 4): at normal priority this stream can end up on the compute stream's queue, and the
-            # captured form's spinning hand-off waits (trainer.py, MRMT3_DDP_GRAPH=1) then block the very kernels they wait
-            # for — measured, profiles/r05_two_graph_probe.txt.  A high-priority stream draws from a queue pool of its own.
-            self._launch = torch.cuda.Stream(device=device, priority=int(os.environ.get("MRMT3_DDP_STREAM_PRIO", "-1")))
+            # Normal priority, like every round so far (MRMT3_DDP_STREAM_PRIO=-1: high).  Two things were learnt about this
+            # stream in round 5 (profiles/r05_two_graph_probe.txt, r05_collectives_ab.txt): HIP deals the streams of one
+            # priority over a few hardware queues, so it MAY share the compute stream's queue — harmless for the eager
+            # collectives (they are ordered behind their bucket anyway), fatal for spinning hand-off waits, which is why
+            # the trainer's two-graph form picks its own stream; and a kernel resident on a second queue costs the compute
+            # graph ~9 us per dependent launch, ~20 % more when that queue is a high-priority one.
+            self._launch = torch.cuda.Stream(device=device, priority=int(os.environ.get("MRMT3_DDP_STREAM_PRIO", "0")))
         return self._launch
 
     def close(self):

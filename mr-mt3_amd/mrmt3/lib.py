@@ -138,7 +138,7 @@ def load():
 MIN_VERSION = 108
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
-                 "gemm_nt_geglubwd", "attn_fwd_resident")
+                 "gemm_nt_geglubwd")
 
 
 def set_knob(name: str, value: int):

@@ -19,14 +19,20 @@ With more than one rank the step is cut into one graph per gradient bucket: the 
 is enqueued EAGERLY between two replays on the launch stream, so it still overlaps the rest of backward and no
 collective is ever captured.  That is the default, because it is the form that needs nothing from RCCL but a plain call.
 
-MRMT3_DDP_GRAPH=1 (round 5) captures the collectives too, as TWO graphs replayed side by side on two streams: the whole
-compute step as one chain (no segment per bucket: a bucket boundary costs 0.07 ms, profiles/r04_bucket_boundary_cost.txt)
-and the buckets' all-reduces (mrmt3_allreduce on the library's own RCCL communicator) as a second chain on the
-collective stream.  The two talk through counting flags in device memory (mrmt3_flag_signal / mrmt3_flag_wait,
-csrc/comm.hip): "bucket i complete" from the compute chain, "all reduced" back before AdamW.  Not one graph with a side
-branch — ROCm 7.2 replays forked graphs serially and slowly — and not the collectives in-line in the compute
-chain (MRMT3_DDP_GRAPH=inline builds that form for A/B): in-line, every all-reduce is exposed instead of hidden under
-the rest of backward.  If the capture of a collective fails the trainer falls back to the segmented form above.
+Round 5 built the two captured forms the round-4 review asked for, as switches (MRMT3_DDP_GRAPH), and measured them at one
+rank with forced collectives (profiles/r05_collectives_ab.txt; neither can be measured at N > 1 here):
+  "inline"  ONE graph, every bucket's all-reduce (mrmt3_allreduce on the library's own RCCL communicator) a node of the compute
+            chain: no segment per bucket (+0.13-0.25 ms over the plain step instead of +0.27-0.35), but the collective is then
+            exposed instead of hidden under the rest of backward;
+  "1"       TWO graphs replayed side by side on two streams — the whole compute step as one chain, the buckets' all-reduces
+            as a second chain on the collective stream — that talk through counting flags in device memory
+            (mrmt3_flag_signal / mrmt3_flag_wait, csrc/comm.hip): "bucket i complete" from the compute chain, "all reduced"
+            back before AdamW.  Not one graph with a side branch: ROCm 7.2 replays forked graphs serially and slowly (DESIGN
+            §3).  Correct (bit-equal to the eager bucketed step) and 3.2-3.8 ms SLOWER per step: while a second hardware
+            queue holds a resident kernel, every dependent launch of the compute graph costs ~9 us more.
+So the default stays the segmented form.  If the capture of a collective fails, or no stream can be found that runs side by
+side with the compute stream (HIP shares a few hardware queues among the streams of a priority:
+profiles/r05_two_graph_probe.txt), the trainer falls back to the segmented form.
 """
 from __future__ import annotations
 
@@ -95,6 +101,7 @@ class Trainer:
         if self.ddp_graph and self.buckets.active:
             self.buckets.native = True                       # the eager warm-up steps use the communicator the capture will
         self._hand = None                                    # flags of the two-graph form (device int32): see _handoffs()
+        self._collective_stream_checked = False
         self.graph_warmup = 2            # eager steps per input signature before capture (tables, workspaces)
         self._graphs = {}                # signature -> _CapturedStep
         self._eager_seen = {}
@@ -150,6 +157,14 @@ class Trainer:
         Returns the (device, un-synchronised) mean loss of this rank."""
         m, eng = self.model, self.engine
         m.train()
+        if self.buckets.active and not self._collective_stream_checked:
+            # once, before the first exchange: the collectives only overlap the rest of backward if their stream sits on
+            # another hardware queue than the compute stream's (profiles/r05_two_graph_probe.txt)
+            self._collective_stream_checked = True
+            if inputs.is_cuda and not self._pick_collective_stream(torch.cuda.current_stream(), inputs.device):
+                import warnings
+                warnings.warn("no stream was found that runs side by side with the compute stream: the gradient all-reduces "
+                              "will queue behind the backward kernels instead of overlapping them")
         if self.lr_lambda is not None:
             self.lr_dev.fill_(self.base_lr * self.lr_lambda(self.host_step))
         if targets_prev is not None and eng.variant == "segmem_v2_with_prev":
@@ -245,6 +260,25 @@ class Trainer:
         torch.cuda.synchronize()
         return int(w[2].item()) == 0
 
+    def _pick_collective_stream(self, compute_stream, device) -> bool:
+        """A collective stream on ANOTHER hardware queue than the compute stream's: on a shared queue an eager all-reduce
+        simply queues between the backward kernels (no overlap), and the two-graph form's spinning hand-off waits would
+        block the kernels they wait for.  HIP deals the streams of one priority over a few queues, so: test the stream the
+        buckets already use, then up to eight fresh ones (MRMT3_DDP_STREAM_PRIO: their priority, default normal — a
+        resident kernel on a HIGH-priority queue slows the compute graph's launches more, profiles/r05_collectives_ab.txt)
+        and keep the first that passes.  False: none did."""
+        prio = int(os.environ.get("MRMT3_DDP_STREAM_PRIO", "0"))
+        first = self.buckets.collective_stream(device)
+        cands = ([first] if first.priority == prio else []) + [None] * 8
+        self._stream_candidates = []
+        for c in cands:
+            s = c if c is not None else torch.cuda.Stream(device=device, priority=prio)
+            self._stream_candidates.append(s)
+            if s.cuda_stream != compute_stream.cuda_stream and self._side_by_side(compute_stream, s):
+                self.buckets.use_collective_stream(s)
+                return True
+        return False
+
     def check_exchange(self):
         """Raises if a hand-off between the compute graph and the collective graph ever timed out (host sync: call it where
         the host waits anyway — end of an epoch, a checkpoint, the end of a benchmark)."""
@@ -293,9 +327,9 @@ class Trainer:
             eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
         mode = self.ddp_graph if self.buckets.active else ""
         before_opt, order = None, []
-        if mode and mode != "inline" and not self._side_by_side(cur, self.buckets.collective_stream(cap.inputs.device)):
-            raise RuntimeError("the compute stream and the collective stream share a hardware queue: two graphs with "
-                               "spinning hand-offs between them would block each other")
+        if mode and mode != "inline" and not self._pick_collective_stream(cur, cap.inputs.device):
+            raise RuntimeError("no stream was found that runs side by side with the compute stream (shared hardware queues): "
+                               "two graphs with spinning hand-offs between them would block each other")
         if mode:
             comm = self.buckets.comm()         # created (and used by the eager steps) before anything captures
             G = self.flat.G

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(AttnParams P)
           if (P.o_lo_out) *(u32x2*)(P.o_lo_out + ooff + dt * 16 + fg * 4) = cl[dt];
         }
       }
-      if (row_ok && fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = m_run[qt] * LN2 + __logf(l);
+      if (row_ok && fg == 0 && P.lse) P.lse[((size_t)b * P.H + h) * P.Lq + qrow[qt]] = fmaf(m_run[qt], LN2, __logf(l));
     }
     if (pass + 1 < AR_Q_PER_WG / 128) {
 #pragma unroll

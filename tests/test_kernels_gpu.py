@@ -439,55 +439,6 @@ def test_attn_fwd_bf16(dev, tile_rows, B, H, Lq, Lk, causal):
     assert _rel(o, oref) < 1e-2 and (o.float() - oref).abs().max() < 3e-2
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk", [(16, 6, 1024, 256), (16, 6, 1024, 320), (3, 2, 1000, 250), (2, 1, 257, 65),
-                                        (64, 6, 1024, 256)])
-@pytest.mark.parametrize("p", [0.0, 0.1])
-def test_attn_fwd_resident_equals_the_streaming_kernel(dev, knobs, B, H, Lq, Lk, p):
-    """csrc/attention_resident.hip: the cross-attention forward with K | V of a (batch, head) resident in LDS (at most 320
-    keys; 256 queries per workgroup, one barrier).  Same tile arithmetic as the streaming kernel, so the SAME BITS: O, the
-    low half of O, the log-sum-exp — with dropout (mask keyed by absolute query / key), with ragged query and key counts,
-    with q and k | v as column slices of wider buffers (the engine's layout).  And held to the f32 reference at p = 0."""
-    from mrmt3 import lib
-    g = torch.Generator(device="cpu").manual_seed(Lq * 5 + Lk)
-    wide_q = (torch.randn(B * Lq, H * 64 + 64, generator=g) * 0.35).to(dev).bfloat16()
-    wide_kv = torch.randn(B * Lk, 2 * H * 64 + 128, generator=g).to(dev).bfloat16()
-    q, k, v = wide_q[:, 64:], wide_kv[:, :H * 64], wide_kv[:, H * 64 + 128:]
-    step = torch.tensor([11], device=dev, dtype=torch.int32)
-    kw = dict(p=p, seed=77, stream_id=9, step=step, want_lo=True)
-    knobs.set("MRMT3_ATTN_RESIDENT_MIN_WG", 1)           # (small cases: the launch rule would leave them to the streaming kernel)
-    res = {}
-    for on in (0, 1):
-        knobs.set("MRMT3_ATTN_RESIDENT", on)
-        before = lib.dispatch_counts()
-        o, lse, o_lo = lib.attn_fwd(q, k, v, B, H, Lq, Lk, False, **kw)
-        after = lib.dispatch_counts()
-        assert after["attn_fwd"] - before["attn_fwd"] == 1
-        assert after["attn_fwd_resident"] - before["attn_fwd_resident"] == on
-        torch.cuda.synchronize()
-        res[on] = (o, lse, o_lo)
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
-    if p == 0.0:
-        oref, lref = _attn_ref(q.contiguous(), k.contiguous(), v.contiguous(), B, H, Lq, Lk, False)
-        assert torch.allclose(res[1][1], lref, atol=2e-3, rtol=1e-4)
-        assert _rel(res[1][0], oref) < 1e-2 and (res[1][0].float() - oref).abs().max() < 3e-2
-
-
-def test_attn_fwd_resident_launch_rule(dev, knobs):
-    """Which launches take the resident kernel by themselves: not causal, at most 320 keys, and at least 512 workgroups of
-    256 queries — the decoder's cross-attention from 22 segments per GPU on; everything else streams."""
-    from mrmt3 import lib
-    knobs.unset("MRMT3_ATTN_RESIDENT")
-    knobs.unset("MRMT3_ATTN_RESIDENT_MIN_WG")
-    for (B, H, Lq, Lk, causal), want in (((22, 6, 1024, 256, False), 1), ((22, 6, 1024, 320, False), 1), ((12, 6, 1024, 256, False), 0),
-                                         ((22, 6, 1024, 384, False), 0), ((64, 6, 256, 256, False), 0), ((22, 6, 1024, 256, True), 0)):
-        q = torch.zeros(B * Lq, H * 64, device=dev, dtype=torch.bfloat16)
-        kv = torch.zeros(B * Lk, H * 64, device=dev, dtype=torch.bfloat16)
-        before = lib.dispatch_counts()["attn_fwd_resident"]
-        lib.attn_fwd(q, kv, kv, B, H, Lq, Lk, causal)
-        assert lib.dispatch_counts()["attn_fwd_resident"] - before == want, (B, H, Lq, Lk, causal)
-
-
 def test_attn_fwd_fused_qkv_layout(dev):
     """q/k/v as column slices of one [rows, 1152] buffer (the fused-QKV GEMM output)."""
     from mrmt3 import lib

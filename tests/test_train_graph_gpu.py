@@ -182,6 +182,10 @@ def test_bucketed_step_with_grouped_weight_gradients_captures_and_equals_eager(d
             losses = [float(tr.train_step(*data[i % 2][:2], audio=True).item()) for i in range(6)]
             torch.cuda.synchronize()
             assert tr.graph_captured == use_graph
+            # the collectives' stream was checked (and if need be replaced) so that it does not share the compute stream's
+            # hardware queue: otherwise an all-reduce queues between the backward kernels instead of overlapping them
+            assert tr._collective_stream_checked
+            assert tr._side_by_side(torch.cuda.current_stream(), tr.buckets.collective_stream(dev))
             if use_graph:
                 cap = next(iter(tr._graphs.values()))
                 assert len(cap.segments) == len(tr.buckets.buckets)
