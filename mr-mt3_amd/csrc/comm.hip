@@ -170,3 +170,41 @@ extern "C" int mrmt3_flag_wait(const int32_t* flag, int32_t* seen, int32_t* err,
   MR_CHECK_LAUNCH("flag_wait");
   return MRMT3_OK;
 }
+
+#ifdef MRMT3_DIAG
+// Diagnostics build only (profiles/tools/overlap_emulation.py): a stand-in for an all-reduce on a box with ONE GPU.  `n_ctas`
+// workgroups (RCCL's channels occupy a few dozen CUs) read and rewrite `buf` in place — values unchanged — until `seconds` have
+// passed: a kernel that is resident on the collective stream's hardware queue, takes memory bandwidth and lasts as long as the
+// real collective would at an assumed bus bandwidth.  What it cannot emulate: launch latency across ranks, stragglers, link errors.
+__global__ void comm_emulate_kernel(float* buf, size_t n, unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  const size_t stride = (size_t)gridDim.x * blockDim.x, chunk = stride * 64;
+  size_t base = 0;
+  do {
+    for (size_t i = base + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n && i < base + chunk; i += stride) {
+      float v = buf[i];
+      asm volatile("" : "+v"(v));
+      buf[i] = v;
+    }
+    base += chunk;
+    if (base >= n) base = 0;
+  } while (__builtin_amdgcn_s_memrealtime() - t0 < ticks);
+}
+// (probe, profiles/tools/wait_value_probe.py) the signal with SYSTEM scope: for a word the command processor polls
+__global__ void flag_signal_sys_kernel(int* flag) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int mrmt3_flag_signal_sys(int32_t* flag, void* stream) {
+  MR_CHECK_ARG(flag, "flag_signal_sys: null pointer");
+  hipLaunchKernelGGL(flag_signal_sys_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)flag);
+  MR_CHECK_LAUNCH("flag_signal_sys");
+  return MRMT3_OK;
+}
+extern "C" int mrmt3_comm_emulate(void* buf, size_t count, double seconds, int n_ctas, void* stream) {
+  MR_CHECK_ARG(buf && count > 0 && seconds >= 0 && n_ctas > 0, "comm_emulate: bad arguments");
+  hipLaunchKernelGGL(comm_emulate_kernel, dim3((unsigned)n_ctas), dim3(256), 0, (hipStream_t)stream, (float*)buf, count,
+                     (unsigned long long)(seconds * 1e8));
+  MR_CHECK_LAUNCH("comm_emulate");
+  return MRMT3_OK;
+}
+#endif
