@@ -97,8 +97,19 @@ class GradBuckets:
             if lo == 0 and "decoder.ckv" in rng:
                 tags = ["decoder.ckv"] + tags          # complete when the last (lowest) decoder layer is done
             add(tags, ("decoder", lo))
-        for hi in range(n_layers_enc - 1, -1, -layers_per_bucket):
-            lo = max(hi - layers_per_bucket + 1, 0)
+        # The LAST bucket's all-reduce is the one nothing overlaps (backward has ended): it holds only the encoder's lowest
+        # `last_layers` layers + the embedding tables (MRMT3_DDP_LAST_BUCKET_LAYERS, default 1: 16 MB instead of the 42 MB of a
+        # full four-layer bucket; one more boundary, a shorter exposed tail — profiles/r05_overlap_emulation.txt).
+        last_layers = max(1, min(layers_per_bucket, int(os.environ.get("MRMT3_DDP_LAST_BUCKET_LAYERS", "1"))))
+        enc_cuts = []                       # (hi, lo) encoder layer ranges, in completion order
+        hi = n_layers_enc - 1
+        while hi >= last_layers:
+            lo = max(hi - layers_per_bucket + 1, last_layers)
+            enc_cuts.append((hi, lo))
+            hi = lo - 1
+        if hi >= 0:
+            enc_cuts.append((hi, 0))
+        for hi, lo in enc_cuts:
             tags = [f"encoder.{i}" for i in range(lo, hi + 1)]
             if hi == n_layers_enc - 1:
                 tags += ["encoder.final"]
@@ -109,8 +120,10 @@ class GradBuckets:
             else:
                 add(tags, ("encoder", lo))
         if has_segmem:
+            # the memory encoder's backward runs between the decoder's and the encoder's (Engine.backward): its gradients are
+            # final there, and their all-reduce hides under the encoder's backward instead of joining the exposed tail
             seg = [t for t in rng if t.startswith("segmem")]
-            add(seg, ("end", 0))
+            add(seg, ("segmem", 0))
         covered = sorted((b["start"], b["end"]) for b in self.buckets)
         pos = 0
         for a, b in covered:

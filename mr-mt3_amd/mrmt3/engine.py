@@ -632,6 +632,8 @@ class Engine:
                 d_enc = d_enc_cat
         if d_mem is not None:
             self.segmem_bwd(tape, d_mem)
+            if on_layer_done is not None:
+                on_layer_done("segmem", 0)                     # the memory encoder's gradients are final (their bucket may leave)
         self.encode_bwd(tape, d_enc, on_layer_done=on_layer_done)
         self.join_wgrad()
         assert not tape.ops, [o["kind"] for o in tape.ops]

@@ -72,7 +72,8 @@ class Trainer:
         cfg = model.cfg
         if grad_exchange_dtype is None and os.environ.get("MRMT3_GRAD_EXCHANGE", "f32") == "bf16":
             grad_exchange_dtype = torch.bfloat16
-        # 4 layers per bucket = 4 buckets of 38-56 MB for MT3Net (5 with segment memory).  A bucket boundary costs 0.07 ms
+        # 4 layers per bucket, the last bucket cut down to the encoder's lowest layer + the embedding tables (ddp.py): 5 buckets of
+        # 47 / 57 / 38 / 28 / 14 MB for MT3Net (6 with segment memory).  A bucket boundary costs 0.07 ms
         # of step time (a graph segment of its own + the grouped weight-gradient launch split there: 16 / 8 / 4 / 2 buckets =
         # 25.26 / 24.70 / 24.40 / 24.23 ms at one rank with forced collectives, plain step 24.17,
         # profiles/r04_bucket_boundary_cost.txt); the LAST bucket's all-reduce is the one nothing overlaps, so fewer, larger
