@@ -45,7 +45,7 @@ def emulated_all_reduce(self, t, stream=None):
         s.wait_stream(torch.cuda.current_stream(t.device))
     n = CFG["n"]
     seconds = 0.0 if n <= 1 else 2.0 * (n - 1) / n * t.numel() * t.element_size() / CFG["busbw"]
-    rc = L.mrmt3_comm_emulate(ctypes.c_void_p(t.data_ptr()), t.numel(), seconds, CFG["ctas"], ctypes.c_void_p(s.cuda_stream))
+    rc = L.mrmt3_comm_emulate(ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size() // 4, seconds, CFG["ctas"], ctypes.c_void_p(s.cuda_stream))   # (words of 4 bytes)
     assert rc == 0, L.mrmt3_last_error()
     ev = torch.cuda.Event()
     ev.record(s)
@@ -90,7 +90,9 @@ def step_ms(variant, B, n, busbw, plain=False, form=""):
 
 print("emulated gradient exchange on one GPU: step ms (graph replays, %d steps), efficiency = plain / emulated; collective stand-in on %d CUs; library %d"
       % (steps, CFG["ctas"], L.mrmt3_version()))
-for variant, B in (("t5", 64), ("t5", 12), ("segmem_v2_with_prev", 64), ("segmem_v2_with_prev", 12)):
+CONFIGS = [(c.split(":")[0], int(c.split(":")[1])) for c in
+           os.environ.get("EMU_CONFIGS", "t5:64,t5:12,segmem_v2_with_prev:64,segmem_v2_with_prev:12").split(",")]
+for variant, B in CONFIGS:
     plain, _, _ = step_ms(variant, B, 1, 300e9, plain=True)
     zero, nb, mb = step_ms(variant, B, 1, 300e9)                    # the exchange's structure alone: zero-length collectives
     print("%s, %d segments per GPU: plain step %.3f ms; %d buckets of %s MB; segments with zero-length collectives %.3f ms (%.3f)"
