@@ -298,7 +298,9 @@ def test_flag_handoffs_order_two_streams_and_time_out_instead_of_hanging(dev):
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     seen = torch.zeros(1, dtype=torch.int32, device=dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
-    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    # (the waiting stream at HIGH priority: HIP deals the streams of one priority over a few hardware queues, and a wait that
+    # shares its queue with the signalling stream blocks the very kernel it waits for — profiles/r05_two_graph_probe.txt)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
     x = torch.zeros(1 << 24, device=dev)
     out = torch.zeros(3, device=dev)
     torch.cuda.synchronize()
