@@ -585,6 +585,12 @@ def main():
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1 or force_coll:
         dist.destroy_process_group()
+    # orderly teardown while the interpreter and the HIP runtime are still whole (captured graphs, page-locked tables): the line
+    # is out; nothing after it should be able to turn the exit code
+    import gc
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

@@ -62,7 +62,8 @@ def pytest_sessionfinish(session, exitstatus):
     """Orderly teardown while the interpreter and the HIP runtime are still whole: drain the device, then collect what the tests
     left behind NOW — captured hipGraphs, page-locked plan tables (`mrmt3_host_free` in `_PinnedTable.__del__`), RCCL communicators
     whose owner went away (`lib.Comm`'s finalizer) — instead of during interpreter shutdown, where the order in which torch, HIP
-    and RCCL unload is not ours to choose (one GPU-suite run of seven this round passed every test and then died on its way out)."""
+    and RCCL unload is not ours to choose (one GPU-suite run of seven this round ended in a fatal-error dump after ~95 % of its usual
+    run time; six identical runs before and after it were clean, and only the tail of that log was kept)."""
     import gc
     try:
         import torch
