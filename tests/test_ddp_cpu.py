@@ -36,6 +36,17 @@ def test_buckets_tile_the_flat_buffer(seg):
     assert "lm_head" in gb.buckets[0]["tags"] and len(gb.buckets) <= 10
     tags = [t for t, _, _ in layer_ranges(flat)]
     assert tags[:3] == ["proj", "decoder_embed_tokens", "encoder.0"]
+    # round 5 layout (chosen under emulated collectives, profiles/r05_overlap_emulation.txt): the LAST bucket — the one all-reduce
+    # nothing overlaps — holds only the encoder's lowest layer and the embedding tables (14 MB, not 42); the memory encoder's
+    # bucket leaves after ITS backward, which runs between the decoder's and the encoder's (Engine.backward)
+    gb = GradBuckets(flat, 8, 8, bool(seg), 4)                          # the trainer's 4 layers per bucket
+    last = [b for b in gb.buckets if b["trigger"] == ("end", 0)]
+    assert len(last) == 1 and sorted(last[0]["tags"]) == ["decoder_embed_tokens", "encoder.0", "proj"]
+    assert (last[0]["end"] - last[0]["start"]) * 4 < 16e6
+    assert [b["trigger"] for b in gb.buckets if any(t.startswith("encoder") for t in b["tags"])] == [("encoder", 4), ("encoder", 1), ("end", 0)]
+    if seg:
+        mem = [b for b in gb.buckets if any(t.startswith("segmem") for t in b["tags"])]
+        assert len(mem) == 1 and mem[0]["trigger"] == ("segmem", 0) and all(t.startswith("segmem") for t in mem[0]["tags"])
 
 
 def _worker(rank, world, port, q, exchange=None):
@@ -52,6 +63,7 @@ def _worker(rank, world, port, q, exchange=None):
         # backward order: decoder layers high -> low, then encoder, then the rest at finish()
         for i in reversed(range(4)):
             gb.on_layer_done("decoder", i)
+        gb.on_layer_done("segmem", 0)            # (the memory encoder's backward sits between the two stacks')
         for i in reversed(range(4)):
             gb.on_layer_done("encoder", i)
         gb.finish()
