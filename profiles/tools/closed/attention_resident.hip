@@ -13,6 +13,10 @@
 // the MFMA operand of O^T = V^T P^T, the epilogue with the low half of O — is attention.hip's, statement for statement:
 // the two kernels give the same bits (tests/test_kernels_gpu.py::test_attn_fwd_resident_equals_the_streaming_kernel), so
 // the backward kernels, which recompute P from the saved log-sum-exp, do not care which one ran.
+//
+// NOT PART OF THE PRODUCT BUILD (round 5: built, bit-identical to the streaming kernel, 0.02-0.10 ms slower in the step;
+// profiles/r05_attn_resident_ab.txt).  To rebuild the experiment: copy into mr-mt3_amd/csrc/, add to SRCS in the Makefile,
+// declare mrmt3_attn_fwd_resident_try in attn_common.h and call it at the top of mrmt3_attn_fwd's bf16 branch.
 #include "common.h"
 
 #include "attn_common.h"
