@@ -3,6 +3,7 @@
 VERDICT r1 "next round" item 1: the host leaves the step (≈600 ctypes launches -> a handful of graph launches), the
 loss trajectory stays bit-identical to the eager path (no float atomics feed gradients), dropout masks still change
 from step to step under replay (device-side step counter), the learning-rate schedule still applies."""
+import os
 import time
 
 import numpy as np
@@ -323,13 +324,32 @@ def test_flag_handoffs_order_two_streams_and_time_out_instead_of_hanging(dev):
     assert int(err.item()) == 1 and out[0].item() == 7.0 and int(seen.item()) == 4
 
 
+def _ran_in_a_process_of_its_own(request) -> bool:
+    """The tests of the captured-collectives forms (MRMT3_DDP_GRAPH, opt-in) run in a child pytest process.  In a fresh process
+    they passed 30 times out of 30 (profiles/tools/r5_session22.sh); at their place near the end of the long-lived suite process —
+    hundreds of graphs, streams and communicators behind it — two suite runs of nine had BOTH captures of the step fail there and
+    the process abort inside the HIP runtime on the eager fallback's device synchronise, taking the whole run with it (an
+    opt-in form's failure must not be able to do that).  Returns True when the test was delegated (and passed)."""
+    import subprocess
+    import sys
+    if os.environ.get("MRMT3_TEST_CHILD") == "1":
+        return False
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", request.node.nodeid, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
+                       cwd=root, env=dict(os.environ, MRMT3_TEST_CHILD="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-2000:])
+    return True
+
+
 @pytest.mark.parametrize("mode", ["1", "inline"])
-def test_collectives_captured_in_the_step_equal_the_eager_bucketed_step(dev, monkeypatch, mode):
+def test_collectives_captured_in_the_step_equal_the_eager_bucketed_step(dev, monkeypatch, mode, request):
     """MRMT3_DDP_GRAPH: the gradient buckets' all-reduces captured — "1": as a second graph replayed beside the compute
     graph on the collective stream, ordered by flag hand-offs; "inline": as nodes of the compute chain.  One rank with the
     collectives forced through the library's own RCCL communicator (every bucket really goes through mrmt3_allreduce).
     No graph segment per bucket any more, and losses, weights and AdamW moments equal the EAGER bucketed step bit for bit
     (DDP's overlap: config/config.yaml:45)."""
+    if _ran_in_a_process_of_its_own(request):
+        return
     import socket
     import torch.distributed as dist
     from mrmt3.trainer import Trainer
@@ -373,12 +393,14 @@ def test_collectives_captured_in_the_step_equal_the_eager_bucketed_step(dev, mon
 
 
 @pytest.mark.parametrize("why", ["collective_refuses_capture", "streams_share_a_hardware_queue"])
-def test_collectives_that_do_not_capture_fall_back_to_graph_segments(dev, monkeypatch, why):
+def test_collectives_that_do_not_capture_fall_back_to_graph_segments(dev, monkeypatch, why, request):
     """"keep the segmented path as the fallback when capture of a collective fails".  Either the collective
     is made to refuse a capturing stream, or the trainer's own check says that the compute and the collective stream do not
     run side by side (one hardware queue for both: the spinning hand-offs would block each other,
     profiles/r05_two_graph_probe.txt).  The trainer warns, captures one graph per bucket with eager collectives instead,
     and its weights equal those of a trainer that never tried."""
+    if _ran_in_a_process_of_its_own(request):
+        return
     import socket
     import warnings
     import torch.distributed as dist
