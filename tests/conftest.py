@@ -62,8 +62,9 @@ def pytest_sessionfinish(session, exitstatus):
     """Orderly teardown while the interpreter and the HIP runtime are still whole: drain the device, then collect what the tests
     left behind NOW — captured hipGraphs, page-locked plan tables (`mrmt3_host_free` in `_PinnedTable.__del__`), RCCL communicators
     whose owner went away (`lib.Comm`'s finalizer) — instead of during interpreter shutdown, where the order in which torch, HIP
-    and RCCL unload is not ours to choose (one GPU-suite run of seven this round ended in a fatal-error dump after ~95 % of its usual
-    run time; six identical runs before and after it were clean, and only the tail of that log was kept)."""
+    and RCCL unload is not ours to choose.  (Added while hunting two aborted suite runs of this round; those turned out to die
+    INSIDE a test of the opt-in captured-collectives forms — tests/test_train_graph_gpu.py now runs them in a child process — but
+    an orderly exit is worth having either way.)"""
     import gc
     try:
         import torch
