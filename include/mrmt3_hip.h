@@ -458,6 +458,23 @@ int mrmt3_allreduce(void* comm, void* buf, size_t count, int dtype, int average,
 int mrmt3_flag_signal(int32_t* flag, void* stream);
 int mrmt3_flag_wait(const int32_t* flag, int32_t* seen, int32_t* err, int timeout_ms, void* stream);
 
+/* ---- capture hygiene (host code that records the training step into hipGraphs: mrmt3/trainer.py) -----------------------
+ * The reference's training loop (train.py:99-103, Lightning) has no graph capture; these exist because this path replays the
+ * step, and a capture that fails must leave the process able to go on with plain launches (the library never aborts).
+ *   mrmt3_stream_capture_status  : 0 = `stream` is not capturing, 1 = capturing, 2 = its capture was invalidated; < 0 = error.
+ *   mrmt3_stream_abandon_capture : if `stream` is (still) in capture mode, ends that capture and destroys whatever graph came
+ *                                  out of it; clears the calling thread's HIP error slot.  Returns the status BEFORE the call.
+ *   mrmt3_runtime_error_pop      : returns (and clears) the calling thread's pending HIP runtime error code — 0 = none — and
+ *                                  writes its name to text[0..n).  A launch wrapper of this library reports whatever is in
+ *                                  that slot as ITS launch failure, so a host that has just survived a failed HIP call of
+ *                                  its own (a refused capture, an RCCL error) empties the slot before launching again.
+ *   mrmt3_abort_trace_install    : opt-in diagnostics — on SIGABRT / SIGSEGV write the native frames of the faulting thread to
+ *                                  `path` (NULL or "": stderr), then hand the signal to the previous handler. */
+int mrmt3_stream_capture_status(void* stream);
+int mrmt3_stream_abandon_capture(void* stream);
+int mrmt3_runtime_error_pop(char* text, int n);
+int mrmt3_abort_trace_install(const char* path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,10 @@ _SIGS = {
     "mrmt3_allreduce": (ci, [vp, vp, csz, ci, ci, vp]),
     "mrmt3_flag_signal": (ci, [vp, vp]),
     "mrmt3_flag_wait": (ci, [vp, vp, vp, ci, vp]),
+    "mrmt3_stream_capture_status": (ci, [vp]),
+    "mrmt3_stream_abandon_capture": (ci, [vp]),
+    "mrmt3_runtime_error_pop": (ci, [C.c_char_p, ci]),
+    "mrmt3_abort_trace_install": (ci, [C.c_char_p]),
 }
 
 
@@ -135,7 +139,7 @@ def load():
     return lib
 
 
-MIN_VERSION = 108
+MIN_VERSION = 109
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
                  "gemm_nt_geglubwd")
@@ -1008,3 +1012,33 @@ def flag_wait(flag: torch.Tensor, seen: torch.Tensor, err: torch.Tensor, timeout
     assert flag.dtype == seen.dtype == err.dtype == torch.int32
     s = C.c_void_p((stream or torch.cuda.current_stream(flag.device)).cuda_stream)
     _check(load().mrmt3_flag_wait(_p(flag), _p(seen), _p(err), int(timeout_ms), s), "flag_wait")
+
+
+# ---- capture hygiene (include/mrmt3_hip.h: "capture hygiene") ------------------------------------------------------------
+_CAPTURE_STATUS = {0: "none", 1: "active", 2: "invalidated"}
+
+
+def stream_capture_status(stream) -> str:
+    """'none' / 'active' / 'invalidated' for a torch stream (or a raw handle)."""
+    h = stream if isinstance(stream, int) else stream.cuda_stream
+    r = load().mrmt3_stream_capture_status(C.c_void_p(h))
+    return _CAPTURE_STATUS.get(r, "error(%d)" % r)
+
+
+def stream_abandon_capture(stream) -> str:
+    """End a capture that `stream` is still in (destroying its graph); returns the status before the call."""
+    h = stream if isinstance(stream, int) else stream.cuda_stream
+    r = load().mrmt3_stream_abandon_capture(C.c_void_p(h))
+    return _CAPTURE_STATUS.get(r, "error(%d)" % r)
+
+
+def runtime_error_pop() -> str:
+    """Name of the calling thread's pending HIP runtime error ('' = none); the slot is empty afterwards."""
+    buf = C.create_string_buffer(96)
+    load().mrmt3_runtime_error_pop(buf, 96)
+    return buf.value.decode()
+
+
+def abort_trace_install(path: str = "") -> None:
+    """Opt-in: native frames of the faulting thread on SIGABRT / SIGSEGV (to `path`, default stderr)."""
+    _check(load().mrmt3_abort_trace_install(path.encode() if path else None), "abort_trace_install")

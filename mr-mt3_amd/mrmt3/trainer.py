@@ -45,6 +45,11 @@ from . import lib
 from .ddp import GradBuckets
 
 
+def _first_line(e) -> str:
+    t = str(e)
+    return t.splitlines()[0] if t else ""
+
+
 class _CapturedStep:
     """One input signature's captured step: graph segments (each followed by the gradient buckets to send), the tail
     graph (AdamW) and the static tensors the graphs read and write."""
@@ -201,22 +206,19 @@ class Trainer:
                         raise
                     # the collectives would not capture: the segmented form (collectives eager between the segments)
                     import warnings
-                    warnings.warn("capturing the gradient all-reduces failed (%s: %s); falling back to one graph per "
-                                  "bucket with eager collectives" % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+                    state = self._after_failed_capture(e)
+                    warnings.warn("capturing the gradient all-reduces failed (%s: %s)%s; falling back to one graph per "
+                                  "bucket with eager collectives" % (type(e).__name__, _first_line(e), state))
                     self.ddp_graph = ""
-                    self.engine.reset_deferred()
-                    self.engine._stream_ctr = 0
-                    torch.cuda.synchronize()
                     cap = self._capture(sig, inputs, labels, targets_prev, audio)
             except Exception as e:     # noqa: BLE001 — whatever a capture trips over, the eager step is still correct
                 # (nothing executed during the failed capture: the step below is the first to run; the launches the
                 # aborted capture had deferred are dropped — _step_body starts with Engine.reset_deferred())
                 import warnings
-                warnings.warn("hipGraph capture of the training step failed (%s: %s); continuing with eager launches"
-                              % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+                state = self._after_failed_capture(e)
+                warnings.warn("hipGraph capture of the training step failed (%s: %s)%s; continuing with eager launches"
+                              % (type(e).__name__, _first_line(e), state))
                 self.use_graph = False
-                self.engine._stream_ctr = 0
-                torch.cuda.synchronize()
                 return self._step_body(inputs, labels, targets_prev, audio)
         self.engine.prepare(True)          # weights written through torch since the last step? rebuild the shadows
         cap.inputs.copy_(inputs, non_blocking=True)
@@ -235,6 +237,61 @@ class Trainer:
         self.buckets.wait()
         cap.tail.replay()
         return cap.loss.clone()            # the graph's own loss scalar is overwritten by the next replay
+
+    # ---- a capture that failed: leave nothing behind -----------------------------------------------------------------
+    def _capture_streams(self):
+        """Every stream a capture of the step can have pulled into capture mode (a capture spreads to each stream that waits
+        on an event of a capturing one: the capture stream itself, the engine's weight-gradient side stream, the collective
+        stream and the candidates the stream pick made), plus the caller's."""
+        out = {"current": torch.cuda.current_stream(), "capture": self._cap_stream, "side": self.engine._side,
+               "collective": self.buckets._launch}
+        for i, s in enumerate(getattr(self, "_stream_candidates", [])):
+            out["candidate%d" % i] = s
+        seen, uniq = set(), {}
+        for k, v in out.items():
+            if v is not None and v.cuda_stream not in seen:
+                seen.add(v.cuda_stream)
+                uniq[k] = v
+        return uniq
+
+    def _after_failed_capture(self, exc) -> str:
+        """Called with the exception of a capture that failed, BEFORE anything else is launched or synchronised.  Ends the
+        capture on every stream that is still in capture mode (an exception between capture_begin and capture_end — or a
+        capture_end that itself fails on an unjoined stream — leaves streams capturing; a device synchronise is illegal
+        then), empties the thread's HIP error slot (the library's launch wrappers report whatever sits there as THEIR launch
+        failure: one stale code would fail the retry and every eager launch after it), drops what the engine had deferred,
+        then drains the device.  Returns a short state report for the warning; with MRMT3_CAPTURE_LOG=<file> the full report
+        (traceback, per-stream capture status, live graph / stream / communicator counts) is appended there."""
+        import gc
+        import traceback
+        left = []
+        for name, st in self._capture_streams().items():
+            was = lib.stream_abandon_capture(st)
+            if was != "none":
+                left.append("%s stream was left capturing (%s)" % (name, was))
+        pending = lib.runtime_error_pop()
+        if pending:
+            left.append("pending HIP error %s" % pending)
+        self.engine.reset_deferred()
+        self.engine._stream_ctr = 0
+        log = os.environ.get("MRMT3_CAPTURE_LOG")
+        if log:
+            objs = gc.get_objects()
+            counts = dict(graphs=sum(isinstance(o, torch.cuda.CUDAGraph) for o in objs),
+                          streams=sum(isinstance(o, torch.cuda.Stream) for o in objs),
+                          comms=sum(isinstance(o, lib.Comm) for o in objs),
+                          trainers=sum(isinstance(o, Trainer) for o in objs))
+            with open(log, "a") as f:
+                f.write("---- failed capture (ddp_graph=%r, world=%d, step=%d)\n%s%s\nlive objects: %s\n"
+                        % (self.ddp_graph, self.world, self.host_step,
+                           "".join(traceback.format_exception(type(exc), exc, exc.__traceback__)),
+                           "; ".join(left) or "no stream left capturing, no pending error", counts))
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError as e:        # a device that cannot be drained: say so in Python instead of going on blind
+            raise RuntimeError("the device could not be synchronised after a failed graph capture (%s); state: %s"
+                               % (_first_line(e), "; ".join(left) or "clean")) from exc
+        return (" [" + "; ".join(left) + "]") if left else ""
 
     # ---- the collectives captured: hand-off flags, the second graph ------------------------------------------------
     def _handoffs(self, device):
@@ -323,9 +380,6 @@ class Trainer:
             cap.segments.append((g, list(fire)))
             begin()
 
-        overlap_was = eng.overlap_wgrad
-        if os.environ.get("MRMT3_GRAPH_LINEAR", "1") == "1":
-            eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
         mode = self.ddp_graph if self.buckets.active else ""
         before_opt, order = None, []
         if mode and mode != "inline" and not self._pick_collective_stream(cur, cap.inputs.device):
@@ -350,6 +404,9 @@ class Trainer:
 
                 def before_opt():
                     lib.flag_wait(hand["flags"][n_b:], hand["seen"][n_b:], hand["err"], hand["timeout_ms"], stream=cs)
+        overlap_was = eng.overlap_wgrad
+        if os.environ.get("MRMT3_GRAPH_LINEAR", "1") == "1":
+            eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
         with torch.cuda.stream(cs):
             begin()
             try:

@@ -16,6 +16,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_abort_trace():
+    """A process taken down by abort() inside HIP / RCCL leaves only Python frames behind (faulthandler); with the library
+    loaded, its handler writes the NATIVE frames of the aborting thread first, then hands over to faulthandler
+    (mrmt3_abort_trace_install).  MRMT3_ABORT_TRACE=0 switches it off; =<path> writes to a file instead of stderr."""
+    where = os.environ.get("MRMT3_ABORT_TRACE", "")
+    if where != "0":
+        try:
+            from mrmt3 import lib
+            lib.abort_trace_install("" if where in ("", "1") else where)
+        except Exception:                  # no library built: the tests that need it say so themselves
+            pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
