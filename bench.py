@@ -57,6 +57,10 @@ def parse(argv=None):
     ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline", action="store_true",
+                    help="with more than one rank: also run the instrumented eager repeat (off by default at N > 1: it is an eager "
+                         "pass on EVERY rank; the N = 1 line carries the roofline)")
+    ap.add_argument("--no-preflight", action="store_true", help="skip the multi-rank start-up checks")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--extra-batch", type=int, default=12, help="also time this per-GPU batch (0 = off)")
     ap.add_argument("--no-extra-workloads", action="store_true",
@@ -92,14 +96,112 @@ def launch_ranks(args, argv, launcher=None, n_visible=None, out_fd=1):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
     env["MRMT3_BENCH_SPAWNED"] = "1"
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err_text = (r.stderr or b"").decode(errors="replace")
+    sys.stderr.write(err_text)                               # the ranks' own lines (`rank r: ...`) stay visible to whoever runs this
+    sys.stderr.flush()
     lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
     if lines:
         os.write(out_fd, (lines[-1] + "\n").encode())
     elif r.returncode == 0:
         sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
         return 3
+    else:
+        # the ranks died without a line of their own (a rank other than 0 failed and the launcher took the rest down, or the
+        # process was killed): say where, from the per-rank stage lines, so that the caller still gets ONE JSON line
+        os.write(out_fd, (json.dumps(failure_record(args.gpus, err_text, r.returncode)) + "\n").encode())
     return r.returncode
+
+
+def failure_record(n_gpus, err_text, returncode):
+    """The JSON line of a multi-rank run that ended without one: the stage each rank reached last (`rank r: stage NAME ...`
+    lines on stderr) and the first failure message."""
+    import re
+    last, failed = {}, None
+    for l in err_text.splitlines():
+        m = re.match(r"rank (\d+): (FAILED at stage|stage) (\S+)(.*)", l)
+        if m:
+            last[int(m.group(1))] = m.group(3)
+            if m.group(2).startswith("FAILED") and failed is None:
+                failed = {"rank": int(m.group(1)), "stage": m.group(3), "message": m.group(4).strip(" :")}
+    stage = failed["stage"] if failed else (min(last.items(), key=lambda kv: STAGES.index(kv[1]) if kv[1] in STAGES else 99)[1]
+                                            if last else "launch")
+    return {"metric": METRIC, "value": None, "unit": "segments/s", "n_gpus": n_gpus, "higher_is_better": True,
+            "error": (failed["message"] if failed else "the ranks exited with code %d without a result line" % returncode),
+            "stage": stage, "failed_rank": failed["rank"] if failed else None,
+            "last_stage_per_rank": {str(k): v for k, v in sorted(last.items())}, "returncode": returncode}
+
+
+METRIC = "train segments/sec (T5-small MT3Net, 256-frame mel, 1024-token target; log-mel + fwd + bwd + AdamW)"
+STAGES = ["rccl_init", "model", "bucket_allreduce", "stream_pick", "capture", "warmup", "timed", "roofline", "report"]
+_STAGE = {"name": "start", "rank": 0}
+
+
+def stage(name, msg=""):
+    """One short stderr line per rank and stage: the first multi-GPU run is one shot, its tail must say how far each rank got."""
+    _STAGE["name"] = name
+    sys.stderr.write("rank %d: stage %s%s\n" % (_STAGE["rank"], name, (" " + msg) if msg else ""))
+    sys.stderr.flush()
+
+
+def preflight(trainer, dev, rank, world, step):
+    """Start-up of a multi-rank run, BEFORE the timed loop: one all-reduce per gradient bucket size through
+    the exact path the step uses, with a checksum; the collective-stream pick; capture of the segmented step + 2 replays and a
+    replica check.  Returns the figures for the JSON line; raises on any mismatch."""
+    out = {}
+    b = trainer.buckets
+    G = trainer.flat.G
+    rows = []
+    for j, bk in enumerate(b.buckets):
+        g = G[bk["start"]:bk["end"]]
+        g.fill_(float(rank + 1))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        w = b._all_reduce(g, b.collective_stream(dev))
+        w.wait()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0)
+        want = world * (world + 1) / 2.0
+        got = (float(g[0].item()), float(g[-1].item()), float(g.double().mean().item()))
+        if any(abs(x - want) > 1e-6 * want for x in got):
+            raise RuntimeError("bucket %d (%d elements): all-reduce checksum %r, expected %g" % (j, g.numel(), got, want))
+        nbytes = g.numel() * 4
+        rows.append({"bucket": j, "MB": nbytes / 1e6, "ms": ms,
+                     "busbw_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9 if world > 1 else None})
+    G.zero_()
+    out["bucket_allreduce"] = rows
+    stage("bucket_allreduce", "%d buckets ok: %s" % (len(rows), ", ".join("%.0f MB %.2f ms" % (r["MB"], r["ms"]) for r in rows)))
+    t0 = time.perf_counter()
+    ok = trainer._pick_collective_stream(torch.cuda.current_stream(), dev)
+    trainer._collective_stream_checked = True
+    out["stream_pick"] = {"side_by_side": bool(ok), "candidates_tried": len(trainer._stream_candidates),
+                          "seconds": time.perf_counter() - t0}
+    stage("stream_pick", "%s after %d candidate(s), %.2f s" % ("side by side" if ok else "NO stream runs beside the compute stream",
+                                                               len(trainer._stream_candidates), out["stream_pick"]["seconds"]))
+    t0 = time.perf_counter()
+    n = 0
+    while trainer.use_graph and not trainer.graph_captured:
+        loss = step()
+        n += 1
+    for _ in range(2):
+        loss = step()
+    torch.cuda.synchronize()
+    if not bool(torch.isfinite(loss).item()):
+        raise RuntimeError("loss is not finite after the first steps: %r" % float(loss.item()))
+    chk = trainer.flat.P.double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    if dist.is_initialized():
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if float(lo.item()) != float(hi.item()):
+        raise RuntimeError("the replicas differ after %d steps: weight checksums %r .. %r" % (n + 2, float(lo.item()), float(hi.item())))
+    cap = next(iter(trainer._graphs.values())) if trainer._graphs else None
+    out["capture"] = {"eager_steps": n, "captured": cap is not None, "graph_segments": (len(cap.segments) + 1) if cap else 0,
+                      "seconds": time.perf_counter() - t0, "replicas_identical": True}
+    stage("capture", "%s, %d steps, %.2f s, replicas identical, loss %.4f"
+          % (("%d graph segments" % out["capture"]["graph_segments"]) if cap else "eager (no graph)", n + 2,
+             out["capture"]["seconds"], float(loss.item())))
+    return out
 
 
 def build_model(variant, dev, dtype=torch.bfloat16):
@@ -402,12 +504,42 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    _STAGE["rank"] = rank
+    try:
+        run(args, world, rank, local, json_fd)
+    except BaseException as e:     # noqa: BLE001 — whatever stops a rank: its stage on stderr, rank 0's JSON line with "error"
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        import traceback
+        traceback.print_exc()
+        msg = "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0])
+        sys.stderr.write("rank %d: FAILED at stage %s: %s\n" % (rank, _STAGE["name"], msg))
+        sys.stderr.flush()
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"metric": METRIC, "value": None, "unit": "segments/s", "n_gpus": world,
+                                           "higher_is_better": True, "error": msg, "stage": _STAGE["name"],
+                                           "failed_rank": rank}) + "\n").encode())
+        os._exit(1)                # no teardown through a half-initialised process group: the launcher ends the other ranks
+
+
+def run(args, world, rank, local, json_fd):
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no CPU fallback"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_coll = os.environ.get("MRMT3_DDP_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ
-    if world > 1 or force_coll:    # (force: the RCCL bucket path at world size 1, for the record in profiles/)
+    multi = world > 1 or force_coll
+    t_init = None
+    if multi:                      # (force: the RCCL bucket path at world size 1, for the record in profiles/)
+        stage("rccl_init", "world %d, device %d, HSA_ENABLE_IPC_MODE_LEGACY=%s" % (world, local, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+        t0 = time.perf_counter()
         dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)       # the communicator is made here, not in init_process_group
+        torch.cuda.synchronize()
+        t_init = time.perf_counter() - t0
+        if float(one.item()) != float(world):
+            raise RuntimeError("first all-reduce: sum of ones over %d ranks came back as %r" % (world, float(one.item())))
+        stage("rccl_init", "done in %.2f s" % t_init)
     ranks_seen = dist.get_world_size() if dist.is_initialized() else 1      # what RCCL's communicator says, not the flag
     assert ranks_seen == world, (ranks_seen, world)
     from mrmt3 import lib
@@ -417,6 +549,8 @@ def main():
     from utils import cosine_warmup_lambda
 
     B = args.batch
+    if multi:
+        stage("model")
     model = build_model(args.variant, dev)
     trainer = Trainer(model, lr=2e-4, lr_lambda=cosine_warmup_lambda(64500, 1289 * 800, min_lr=1e-4))
     n_samples = args.mel_frames * 128
@@ -433,11 +567,20 @@ def main():
 
     # setup, not measured: the trainer runs its first steps eagerly and then captures the step into hipGraphs
     # (mrmt3/trainer.py); make sure that has happened before the W warm-up steps, whatever W is
+    pre = None
+    if multi and not args.no_preflight:
+        pre = preflight(trainer, dev, rank, world,
+                        lambda: trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True))
+        pre["rccl_init_seconds"] = t_init
     while trainer.use_graph and not trainer.graph_captured:
         trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
+    if multi:
+        stage("warmup")
     for _ in range(args.warmup):
         loss = trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
     sync()
+    if multi:
+        stage("timed")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.train_step(audio, labels, None if prev is None else prev.clone(), audio=True)
@@ -452,8 +595,10 @@ def main():
     trainer.check_exchange()                       # (two-graph form: no hand-off between the graphs ever timed out)
     seg_per_s = world * B * args.steps / dt
 
+    if multi:
+        stage("timed", "%.2f ms per step" % (1e3 * dt / args.steps))
     res = {
-        "metric": "train segments/sec (T5-small MT3Net, 256-frame mel, 1024-token target; log-mel + fwd + bwd + AdamW)",
+        "metric": METRIC,
         "value": seg_per_s, "unit": "segments/s", "n_gpus": world, "ranks_seen": ranks_seen,
         "launched_by": ("bench.py --gpus %d -> child torch.distributed.run" % args.gpus if os.environ.get("MRMT3_BENCH_SPAWNED")
                         else "external launcher (WORLD_SIZE=%d)" % world if "WORLD_SIZE" in os.environ else "single process"),
@@ -485,6 +630,10 @@ def main():
         "model_tflops": None if flop_per_seg is None else seg_per_s * flop_per_seg / 1e12 / world,
         "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
+    if pre is not None:
+        res["preflight"] = pre
+    # the instrumented eager repeat: at N = 1 by default; at N > 1 only with --roofline (it is an eager pass on every rank)
+    do_roofline = not args.no_roofline and (world == 1 or args.roofline)
     if rank == 0 and world == 1 and args.extra_batch > 0:
         # the reference's own per-GPU batch (config_slakh_segmem.yaml: num_rows_per_batch 12)
         Bx = args.extra_batch
@@ -501,7 +650,9 @@ def main():
         res["train_b%d" % Bx] = {"segments_per_gpu": Bx, "ms_per_step": 1e3 * dtx / args.steps,
                                  "segments_per_s": Bx * args.steps / dtx,
                                  "model_tflops": None if flop_per_seg is None else Bx * args.steps / dtx * flop_per_seg / 1e12}
-    if not args.no_roofline:
+    if do_roofline:
+        if multi:
+            stage("roofline")
         # every rank repeats the steps (the gradient exchange is collective); rank 0 keeps the timings.
         # The replayed graph is ONE chain of kernels (the grouped weight-gradient launch included), so the eager repeat
         # runs everything on one stream too and every launch is timed the way the graph executes it.
@@ -512,7 +663,7 @@ def main():
         fam = roofline_pass(trainer, audio, labels, None if prev is None else prev.clone(), n_rf)
         eng.overlap_wgrad = was
         trainer.use_graph = graph_was
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and do_roofline:
         dom = "gemm_nt_bf16"        # forward + dgrad Linear layers: the family with the most FLOPs per step
 
         def rate(v):
@@ -580,6 +731,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     sync()
+    if multi:
+        stage("report")
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
