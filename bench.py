@@ -119,7 +119,7 @@ def failure_record(n_gpus, err_text, returncode):
     import re
     last, failed = {}, None
     for l in err_text.splitlines():
-        m = re.match(r"rank (\d+): (FAILED at stage|stage) (\S+)(.*)", l)
+        m = re.match(r"rank (\d+): (FAILED at stage|stage) ([A-Za-z0-9_]+)(.*)", l)
         if m:
             last[int(m.group(1))] = m.group(3)
             if m.group(2).startswith("FAILED") and failed is None:
@@ -592,7 +592,6 @@ def run(args, world, rank, local, json_fd):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
-    trainer.check_exchange()                       # (two-graph form: no hand-off between the graphs ever timed out)
     seg_per_s = world * B * args.steps / dt
 
     if multi:
@@ -614,11 +613,8 @@ def run(args, world, rank, local, json_fd):
         "final_loss": final_loss,
         "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
         "step_graph": bool(trainer.use_graph and trainer.graph_captured),
-        # graphs replayed per step: the compute step (one per gradient bucket when collectives run eagerly between
-        # them) + AdamW's tail, + 1 when the collectives are a graph of their own (MRMT3_DDP_GRAPH=1)
-        "graph_segments": ((lambda c: len(c.segments) + 1 + (1 if c.comm is not None else 0))(next(iter(trainer._graphs.values())))
-                           if trainer._graphs else 0),
-        "collectives_captured": (trainer.ddp_graph or "no") if trainer.buckets.active else None,
+        # graphs replayed per step: the compute step (one per gradient bucket: the collectives run eagerly between them) + AdamW's tail
+        "graph_segments": (len(next(iter(trainer._graphs.values())).segments) + 1) if trainer._graphs else 0,
         "collectives": ("rccl%s, %d buckets per step%s" % (" through the C ABI (mrmt3_allreduce)" if trainer.buckets.native else " through torch.distributed",
                                                            len(trainer.buckets.buckets), " (forced at world 1)" if force_coll and world == 1 else "")
                         if trainer.buckets.active else "none (world 1)"),
@@ -722,7 +718,7 @@ def run(args, world, rank, local, json_fd):
         res["train_long_context"] = timed_workload(dev, "segmem_v2_with_prev", 12, 2048 * 128, args.steps, FLOP_PER_SEG_LONG,
                                                    lr=1e-5)
     sync()
-    trainer.buckets.close()                        # the library's own communicator, if one was made (MRMT3_DDP_NATIVE / _GRAPH)
+    trainer.close()                                # graphs first, then the library's own communicator if one was made (MRMT3_DDP_NATIVE)
     if rank == 0 and not args.no_inference:
         del trainer, model
         torch.cuda.empty_cache()

@@ -207,15 +207,17 @@ class GradBuckets:
         if self._launch is None or self._launch.device != device:
             # Normal priority, like every round so far (MRMT3_DDP_STREAM_PRIO=-1: high).  Two things were learnt about this
             # stream in round 5 (profiles/r05_two_graph_probe.txt, r05_collectives_ab.txt): HIP deals the streams of one
-            # priority over a few hardware queues, so it MAY share the compute stream's queue — harmless for the eager
-            # collectives (they are ordered behind their bucket anyway), fatal for spinning hand-off waits, which is why
-            # the trainer's two-graph form picks its own stream; and a kernel resident on a second queue costs the compute
-            # graph ~9 us per dependent launch, ~20 % more when that queue is a high-priority one.
+            # priority over a few hardware queues, so it MAY share the compute stream's queue — then the collectives queue
+            # between the backward kernels and overlap nothing, which is why the trainer tests and, if need be, replaces this
+            # stream before the first exchange (Trainer._pick_collective_stream); and a kernel resident on a second queue
+            # costs the compute graph ~9 us per dependent launch, ~20 % more when that queue is a high-priority one.
             self._launch = torch.cuda.Stream(device=device, priority=int(os.environ.get("MRMT3_DDP_STREAM_PRIO", "0")))
         return self._launch
 
     def close(self):
-        """Release the library's communicator (native path); the buckets stay usable — the next exchange makes a new one."""
+        """Release the library's communicator (native path); the buckets stay usable — the next exchange makes a new one.
+        (No collective is ever captured into a graph, so no graph can outlive the communicator whose kernels it holds;
+        owners call Trainer.close(), which drops the step's graphs first all the same.)"""
         if self._comm is not None:
             self._comm.close()
             self._comm = None

@@ -236,8 +236,7 @@ def main(argv=None):
         trainer.save_checkpoint(os.path.join(out_dir, "last.ckpt"), epoch=0 if synthetic else last_ep)
         trainer.save_checkpoint(os.path.join(out_dir, "last.pt"))
         print(f"Saved model in {os.path.join(out_dir, 'last.pt')}.", flush=True)
-    trainer.check_exchange()             # (collectives captured as a graph: no hand-off ever timed out)
-    trainer.buckets.close()              # the library's own RCCL communicator (MRMT3_DDP_NATIVE / MRMT3_DDP_GRAPH), before torch's
+    trainer.close()                      # captured graphs, then the library's own RCCL communicator (MRMT3_DDP_NATIVE), before torch's
     if world > 1:
         dist.destroy_process_group()
     return task

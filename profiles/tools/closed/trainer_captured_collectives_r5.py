@@ -19,20 +19,20 @@ With more than one rank the step is cut into one graph per gradient bucket: the 
 is enqueued EAGERLY between two replays on the launch stream, so it still overlaps the rest of backward and no
 collective is ever captured.  That is the default, because it is the form that needs nothing from RCCL but a plain call.
 
-Captured collectives (one graph with the all-reduces in-line; two graphs side by side with flag hand-offs) were built and
-measured in round 5 and lost (+0.13-0.25 ms exposed / +3.2-3.8 ms: profiles/r05_collectives_ab.txt); round 6 took them out of
-the product (profiles/tools/closed/trainer_captured_collectives_r5.py keeps the code for the record).
-
-A capture that fails.  Whatever trips a capture (a kernel that refuses, an illegal call inside it), the step goes on with plain
-launches — and nothing of the failed capture may stay behind, because of how torch 2.10 / ROCm 7.2 behave (round 6 root cause of
-the round-5 abort, profiles/r06_capture_abort_root_cause.txt): (1) the cyclic garbage collector running INSIDE a capture frees
-older trainers' graphs, page-locked tables and communicators — HIP calls that are illegal while the thread captures — and
-invalidates the capture; (2) `CUDAGraph.capture_begin` on a stream that is still in capture mode raises AFTER the graph has noted
-the default generator's state but BEFORE that state has noted the graph, and destroying such a graph object throws inside
-`~CUDAGraph` -> std::terminate -> SIGABRT.  So: garbage is collected BEFORE a capture and the collector is off during it; a
-capture never begins on a stream whose status is not "none" (mrmt3_stream_capture_status); after a failure every participating
-stream is taken out of capture mode (mrmt3_stream_abandon_capture), the capture stream is replaced by a fresh one, and a graph
-object whose capture_begin raised is never destroyed (`_retire`).
+Round 5 built the two captured forms the round-4 review asked for, as switches (MRMT3_DDP_GRAPH), and measured them at one
+rank with forced collectives (profiles/r05_collectives_ab.txt; neither can be measured at N > 1 here):
+  "inline"  ONE graph, every bucket's all-reduce (mrmt3_allreduce on the library's own RCCL communicator) a node of the compute
+            chain: no segment per bucket (+0.13-0.25 ms over the plain step instead of +0.27-0.35), but the collective is then
+            exposed instead of hidden under the rest of backward;
+  "1"       TWO graphs replayed side by side on two streams — the whole compute step as one chain, the buckets' all-reduces
+            as a second chain on the collective stream — that talk through counting flags in device memory
+            (mrmt3_flag_signal / mrmt3_flag_wait, csrc/comm.hip): "bucket i complete" from the compute chain, "all reduced"
+            back before AdamW.  Not one graph with a side branch: ROCm 7.2 replays forked graphs serially and slowly (DESIGN
+            §3).  Correct (bit-equal to the eager bucketed step) and 3.2-3.8 ms SLOWER per step: while a second hardware
+            queue holds a resident kernel, every dependent launch of the compute graph costs ~9 us more.
+So the default stays the segmented form.  If the capture of a collective fails, or no stream can be found that runs side by
+side with the compute stream (HIP shares a few hardware queues among the streams of a priority:
+profiles/r05_two_graph_probe.txt), the trainer falls back to the segmented form.
 """
 from __future__ import annotations
 
@@ -45,29 +45,13 @@ from . import lib
 from .ddp import GradBuckets
 
 
-_RETIRED = []
-
-
-def _retire(graph) -> None:
-    """A CUDAGraph whose capture_begin raised must never be destroyed: torch 2.10's ~CUDAGraph un-registers the graph from the
-    generator state it noted in capture_begin, and when capture_begin raised between the two registrations that check throws
-    inside the destructor and the process aborts.  One reference is leaked on purpose (a few hundred bytes)."""
-    import ctypes
-    _RETIRED.append(graph)
-    ctypes.pythonapi.Py_IncRef(ctypes.py_object(graph))
-
-
-def _first_line(e) -> str:
-    t = str(e)
-    return t.splitlines()[0] if t else ""
-
-
 class _CapturedStep:
     """One input signature's captured step: graph segments (each followed by the gradient buckets to send), the tail
     graph (AdamW) and the static tensors the graphs read and write."""
 
     def __init__(self):
         self.segments, self.tail = [], None
+        self.comm = None          # two-graph form: the chain of all-reduces, replayed on the collective stream
         self.inputs = self.labels = self.prev = self.loss = None
 
 
@@ -107,6 +91,17 @@ class Trainer:
         # every dropout mask of a step is salted in-kernel by the device step counter (see module docstring)
         self.engine.step_dev = self.step_dev
         self.use_graph = (os.environ.get("MRMT3_TRAIN_GRAPH", "1") != "0") if graph is None else bool(graph)
+        # "" (default): one graph per gradient bucket, collectives eager between them; "1": two graphs side by side, the
+        # collectives captured (needs the f32 exchange and the library's own communicator); "inline": one graph, collectives
+        # in the compute chain (A/B only).  See the module docstring.
+        self.ddp_graph = os.environ.get("MRMT3_DDP_GRAPH", "")
+        if self.ddp_graph in ("0", "off"):
+            self.ddp_graph = ""
+        if self.ddp_graph and self.buckets.exchange_dtype is not None:
+            self.ddp_graph = ""                              # the compressed exchange stages copies around the collective
+        if self.ddp_graph and self.buckets.active:
+            self.buckets.native = True                       # the eager warm-up steps use the communicator the capture will
+        self._hand = None                                    # flags of the two-graph form (device int32): see _handoffs()
         self._collective_stream_checked = False
         self.graph_warmup = 2            # eager steps per input signature before capture (tables, workspaces)
         self._graphs = {}                # signature -> _CapturedStep
@@ -119,9 +114,10 @@ class Trainer:
         return sp.logmel_segments(audio, out_bf16=(self.engine.dt == torch.bfloat16))
 
     # ---- one step's device work (identical in eager mode, under capture and — by replay — afterwards) ------------
-    def _step_body(self, inputs, labels, targets_prev, audio, cut=None):
+    def _step_body(self, inputs, labels, targets_prev, audio, cut=None, before_optimizer=None):
         """Enqueues one optimizer step.  `cut(bucket_indices)` is called where a gradient bucket is complete (only
-        when collectives will run): under capture it closes the current graph segment."""
+        when collectives will run); under capture it closes the current graph segment (or, with the collectives
+        captured, signals the bucket to the collective graph).  `before_optimizer()` runs right before AdamW."""
         eng, flat = self.engine, self.flat
         eng.reset_deferred()                                 # nothing of an aborted capture / failed step leaks into this one
         eng._stream_ctr = 0                                  # dropout site ids are per-step (step_dev salts them)
@@ -152,6 +148,8 @@ class Trainer:
             active = self.buckets.active
             eng.backward(tape, dl, on_layer_done=layer_done if active else None)     # ends with join_wgrad()
             cut([j for j in range(len(self.buckets.buckets)) if j not in sent] if active else [])
+        if before_optimizer is not None:
+            before_optimizer()
         flat.adamw_step(self.lr_dev, self.step_dev, self.betas, self.eps, self.wd, grad_scale=1.0 / self.world)
         return loss
 
@@ -196,15 +194,29 @@ class Trainer:
                 self._eager_seen[sig] = seen + 1
                 return self._step_body(inputs, labels, targets_prev, audio)
             try:
-                cap = self._capture(sig, inputs, labels, targets_prev, audio)
+                try:
+                    cap = self._capture(sig, inputs, labels, targets_prev, audio)
+                except Exception as e:     # noqa: BLE001
+                    if not (self.ddp_graph and self.buckets.active):
+                        raise
+                    # the collectives would not capture: the segmented form (collectives eager between the segments)
+                    import warnings
+                    warnings.warn("capturing the gradient all-reduces failed (%s: %s); falling back to one graph per "
+                                  "bucket with eager collectives" % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+                    self.ddp_graph = ""
+                    self.engine.reset_deferred()
+                    self.engine._stream_ctr = 0
+                    torch.cuda.synchronize()
+                    cap = self._capture(sig, inputs, labels, targets_prev, audio)
             except Exception as e:     # noqa: BLE001 — whatever a capture trips over, the eager step is still correct
                 # (nothing executed during the failed capture: the step below is the first to run; the launches the
-                # aborted capture had deferred are dropped — _after_failed_capture and _step_body reset them)
+                # aborted capture had deferred are dropped — _step_body starts with Engine.reset_deferred())
                 import warnings
-                state = self._after_failed_capture(e)
-                warnings.warn("hipGraph capture of the training step failed (%s: %s)%s; continuing with eager launches"
-                              % (type(e).__name__, _first_line(e), state))
+                warnings.warn("hipGraph capture of the training step failed (%s: %s); continuing with eager launches"
+                              % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
                 self.use_graph = False
+                self.engine._stream_ctr = 0
+                torch.cuda.synchronize()
                 return self._step_body(inputs, labels, targets_prev, audio)
         self.engine.prepare(True)          # weights written through torch since the last step? rebuild the shadows
         cap.inputs.copy_(inputs, non_blocking=True)
@@ -212,6 +224,10 @@ class Trainer:
         if cap.prev is not None:
             cap.prev.copy_(targets_prev, non_blocking=True)
         self.buckets.reset()
+        if cap.comm is not None:           # two graphs side by side; they order themselves through the hand-off flags
+            ks = self.buckets.collective_stream(cap.inputs.device)
+            with torch.cuda.stream(ks):
+                cap.comm.replay()
         for graph, fire in cap.segments:
             graph.replay()
             for idx in fire:
@@ -220,82 +236,38 @@ class Trainer:
         cap.tail.replay()
         return cap.loss.clone()            # the graph's own loss scalar is overwritten by the next replay
 
-    # ---- a capture that failed: leave nothing behind -----------------------------------------------------------------
-    def _capture_streams(self):
-        """Every stream a capture of the step can have pulled into capture mode (a capture spreads to each stream that waits
-        on an event of a capturing one: the capture stream itself, the engine's weight-gradient side stream, the collective
-        stream and the candidates the stream pick made), plus the caller's."""
-        out = {"current": torch.cuda.current_stream(), "capture": self._cap_stream, "side": self.engine._side,
-               "collective": self.buckets._launch}
-        for i, s in enumerate(getattr(self, "_stream_candidates", [])):
-            out["candidate%d" % i] = s
-        seen, uniq = set(), {}
-        for k, v in out.items():
-            if v is not None and v.cuda_stream not in seen:
-                seen.add(v.cuda_stream)
-                uniq[k] = v
-        return uniq
+    # ---- the collectives captured: hand-off flags, the second graph ------------------------------------------------
+    def _handoffs(self, device):
+        """Device words of the two-graph form: flags[j] counts completions of bucket j (compute graph), flags[n] counts
+        "every bucket reduced" (collective graph); seen[] are the waiting sides' own counters; err is raised by a wait that
+        timed out (check_exchange())."""
+        if self._hand is None:
+            n = len(self.buckets.buckets) + 1
+            self._hand = dict(flags=torch.zeros(n, dtype=torch.int32, device=device),
+                              seen=torch.zeros(n, dtype=torch.int32, device=device),
+                              err=torch.zeros(1, dtype=torch.int32, device=device),
+                              timeout_ms=int(os.environ.get("MRMT3_DDP_GRAPH_TIMEOUT_MS", "20000")))
+        return self._hand
 
-    def _after_failed_capture(self, exc) -> str:
-        """Called with the exception of a capture that failed, BEFORE anything else is launched or synchronised.  Ends the
-        capture on every stream that is still in capture mode (an exception between capture_begin and capture_end — or a
-        capture_end that itself fails on an unjoined stream — leaves streams capturing; a device synchronise is illegal
-        then), empties the thread's HIP error slot (the library's launch wrappers report whatever sits there as THEIR launch
-        failure: one stale code would fail the retry and every eager launch after it), drops what the engine had deferred,
-        then drains the device.  Returns a short state report for the warning; with MRMT3_CAPTURE_LOG=<file> the full report
-        (traceback, per-stream capture status, live graph / stream / communicator counts) is appended there."""
-        import gc
-        import traceback
-        left = []
-        for name, st in self._capture_streams().items():
-            was = lib.stream_abandon_capture(st)
-            if was != "none":
-                left.append("%s stream was left capturing (%s)" % (name, was))
-        pending = lib.runtime_error_pop()
-        if pending:
-            left.append("pending HIP error %s" % pending)
-        self._cap_stream = None                              # a later capture (another input shape) gets a fresh stream
-        self.engine.reset_deferred()
-        self.engine._stream_ctr = 0
-        log = os.environ.get("MRMT3_CAPTURE_LOG")
-        if log:
-            objs = gc.get_objects()
-            counts = dict(graphs=sum(isinstance(o, torch.cuda.CUDAGraph) for o in objs),
-                          streams=sum(isinstance(o, torch.cuda.Stream) for o in objs),
-                          comms=sum(isinstance(o, lib.Comm) for o in objs),
-                          trainers=sum(isinstance(o, Trainer) for o in objs))
-            with open(log, "a") as f:
-                f.write("---- failed capture (world=%d, step=%d)\n%s%s\nlive objects: %s\n"
-                        % (self.world, self.host_step,
-                           "".join(traceback.format_exception(type(exc), exc, exc.__traceback__)),
-                           "; ".join(left) or "no stream left capturing, no pending error", counts))
-        try:
-            torch.cuda.synchronize()
-        except RuntimeError as e:        # a device that cannot be drained: say so in Python instead of going on blind
-            raise RuntimeError("the device could not be synchronised after a failed graph capture (%s); state: %s"
-                               % (_first_line(e), "; ".join(left) or "clean")) from exc
-        return (" [" + "; ".join(left) + "]") if left else ""
-
-    # ---- which stream the collectives run on --------------------------------------------------------------------------
-    def _side_by_side(self, compute_stream, collective_stream, timeout_ms: int = 100) -> bool:
+    def _side_by_side(self, compute_stream, collective_stream) -> bool:
         """Do kernels of the two streams run side by side?  A spinning wait on the collective stream, then its signal on
         the compute stream: if the wait times out, both streams feed ONE hardware queue (HIP shares a few queues among
-        the streams of a priority).  Eager, 0.1 ms when fine, `timeout_ms` when not."""
+        the streams of a priority) and the two-graph form must not be used.  Eager, once per capture, 0.1 ms when fine."""
         dev = self.flat.G.device
         w = torch.zeros(3, dtype=torch.int32, device=dev)            # flag, seen, err
         torch.cuda.synchronize()
-        lib.flag_wait(w[0:1], w[1:2], w[2:3], timeout_ms, stream=collective_stream)
+        lib.flag_wait(w[0:1], w[1:2], w[2:3], 250, stream=collective_stream)
         lib.flag_signal(w[0:1], stream=compute_stream)
         torch.cuda.synchronize()
         return int(w[2].item()) == 0
 
     def _pick_collective_stream(self, compute_stream, device) -> bool:
         """A collective stream on ANOTHER hardware queue than the compute stream's: on a shared queue an eager all-reduce
-        simply queues between the backward kernels and overlaps nothing (profiles/r05_two_graph_probe.txt).  HIP deals the
-        streams of one priority over a few queues, so: test the stream the buckets already use, then up to eight fresh ones
-        (MRMT3_DDP_STREAM_PRIO: their priority, default normal — a resident kernel on a HIGH-priority queue slows the compute
-        graph's launches more, profiles/r05_collectives_ab.txt) and keep the first that passes.  At most nine probes of
-        100 ms: under a second in all.  False: none did."""
+        simply queues between the backward kernels (no overlap), and the two-graph form's spinning hand-off waits would
+        block the kernels they wait for.  HIP deals the streams of one priority over a few queues, so: test the stream the
+        buckets already use, then up to eight fresh ones (MRMT3_DDP_STREAM_PRIO: their priority, default normal — a
+        resident kernel on a HIGH-priority queue slows the compute graph's launches more, profiles/r05_collectives_ab.txt)
+        and keep the first that passes.  False: none did."""
         prio = int(os.environ.get("MRMT3_DDP_STREAM_PRIO", "0"))
         first = self.buckets.collective_stream(device)
         cands = ([first] if first.priority == prio else []) + [None] * 8
@@ -308,21 +280,20 @@ class Trainer:
                 return True
         return False
 
+    def check_exchange(self):
+        """Raises if a hand-off between the compute graph and the collective graph ever timed out (host sync: call it where
+        the host waits anyway — end of an epoch, a checkpoint, the end of a benchmark)."""
+        if self._hand is not None and int(self._hand["err"].item()) != 0:
+            raise RuntimeError("data-parallel step: a graph hand-off timed out (a gradient bucket was never signalled or "
+                               "never reduced); the gradients of that step are not the all-reduced ones")
+
     def _capture(self, sig, inputs, labels, targets_prev, audio):
         """Record the step once (nothing executes during capture); `train_step` then replays it, this step included."""
-        import gc
         eng = self.engine
         cur = torch.cuda.current_stream()
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream()
         cs = self._cap_stream
-        st = lib.stream_capture_status(cs)
-        if st != "none":                   # (checked again before every segment's capture_begin: see begin())
-            raise RuntimeError("the capture stream is still in capture mode (%s): not beginning another capture on it" % st)
-        # Garbage first, while HIP calls are legal: an older trainer's graphs (hipGraphExecDestroy), page-locked plan tables
-        # (hipHostFree) or communicator freed by the cyclic collector in the MIDDLE of the capture invalidate it ("operation
-        # failed due to a previous error during capture" — seen only in long-lived processes with such garbage pending).
-        gc.collect()
         torch.cuda.synchronize()           # nothing of the eager steps (collectives included) is in flight during capture
         eng.prepare(True)
         cap = _CapturedStep()
@@ -333,29 +304,19 @@ class Trainer:
         state = {"g": None}
 
         def begin():
-            # never on a stream that is not cleanly out of capture mode: torch's capture_begin would raise half-way through
-            # its registrations and leave a graph object whose destructor aborts the process (module docstring)
-            st = lib.stream_capture_status(cs)
-            if st != "none":
-                raise RuntimeError("the capture stream is still in capture mode (%s): not beginning another capture on it" % st)
             # thread-local capture mode: the process group's watchdog thread polls the events of earlier collectives
             # (hipEventQuery) whenever it likes; under the default global mode that call is illegal while ANY thread
             # captures and the watchdog takes the process down (seen with RCCL at world size 1, forced collectives)
             g = torch.cuda.CUDAGraph()
-            try:
-                if pool is None:
-                    g.capture_begin(capture_error_mode="thread_local")
-                else:
-                    g.capture_begin(pool=pool, capture_error_mode="thread_local")
-            except Exception:
-                _retire(g)
-                raise
+            if pool is None:
+                g.capture_begin(capture_error_mode="thread_local")
+            else:
+                g.capture_begin(pool=pool, capture_error_mode="thread_local")
             state["g"] = g
 
         def cut(fire):
             nonlocal pool
             g = state["g"]
-            state["g"] = None
             g.capture_end()
             if pool is None:
                 pool = g.pool()
@@ -363,48 +324,68 @@ class Trainer:
             begin()
 
         overlap_was = eng.overlap_wgrad
-        gc_was = gc.isenabled()
-        gc.disable()
-        try:
-            if os.environ.get("MRMT3_GRAPH_LINEAR", "1") == "1":
-                eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
-            with torch.cuda.stream(cs):
-                begin()
+        if os.environ.get("MRMT3_GRAPH_LINEAR", "1") == "1":
+            eng.overlap_wgrad = False          # one chain of nodes, no fork/join edges in the graph
+        mode = self.ddp_graph if self.buckets.active else ""
+        before_opt, order = None, []
+        if mode and mode != "inline" and not self._pick_collective_stream(cur, cap.inputs.device):
+            raise RuntimeError("no stream was found that runs side by side with the compute stream (shared hardware queues): "
+                               "two graphs with spinning hand-offs between them would block each other")
+        if mode:
+            comm = self.buckets.comm()         # created (and used by the eager steps) before anything captures
+            G = self.flat.G
+            if mode == "inline":
+                def cut(fire):                 # noqa: F811 — the collective as a node of the compute chain itself
+                    for j in fire:
+                        b = self.buckets.buckets[j]
+                        comm.allreduce(G[b["start"]:b["end"]], stream=cs)
+            else:
+                hand = self._handoffs(cap.inputs.device)
+                n_b = len(self.buckets.buckets)
+
+                def cut(fire):                 # noqa: F811 — "bucket j is complete" to the collective graph
+                    for j in fire:
+                        lib.flag_signal(hand["flags"][j:j + 1], stream=cs)
+                        order.append(j)
+
+                def before_opt():
+                    lib.flag_wait(hand["flags"][n_b:], hand["seen"][n_b:], hand["err"], hand["timeout_ms"], stream=cs)
+        with torch.cuda.stream(cs):
+            begin()
+            try:
+                cap.loss = self._step_body(cap.inputs, cap.labels, cap.prev, audio, cut=cut, before_optimizer=before_opt)
+                state["g"].capture_end()
+            except Exception:
                 try:
-                    cap.loss = self._step_body(cap.inputs, cap.labels, cap.prev, audio, cut=cut)
-                    g, state["g"] = state["g"], None
-                    g.capture_end()
-                    cap.tail = g
+                    state["g"].capture_end()
                 except Exception:
-                    g = state["g"]
-                    if g is not None:              # a capture is open: end it here.  If it is already invalidated this raises
-                        try:                       # too: _after_failed_capture then takes the stream out of capture mode, and
-                            g.capture_end()        # the allocator is told by hand that this capture no longer routes
-                        except Exception:          # allocations into its pool (capture_end raised before it got there)
-                            try:
-                                torch._C._cuda_endAllocateToPool(cap.inputs.device.index or 0, g.pool())
-                            except Exception:
-                                pass
-                    raise
-        finally:
-            eng.overlap_wgrad = overlap_was
-            if gc_was:
-                gc.enable()
+                    pass
+                raise
+            finally:
+                eng.overlap_wgrad = overlap_was
+            cap.tail = state["g"]
+        if mode and mode != "inline":
+            # the second graph: for every bucket in the order backward completes them — wait for its signal, all-reduce it;
+            # then "all reduced" back to the compute chain
+            ks = self.buckets.collective_stream(cap.inputs.device)
+            ks.wait_stream(cs)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(ks):
+                g2.capture_begin(pool=pool if pool is not None else cap.tail.pool(), capture_error_mode="thread_local")
+                try:
+                    for j in order:
+                        b = self.buckets.buckets[j]
+                        lib.flag_wait(hand["flags"][j:j + 1], hand["seen"][j:j + 1], hand["err"], hand["timeout_ms"], stream=ks)
+                        comm.allreduce(G[b["start"]:b["end"]], stream=ks)
+                    lib.flag_signal(hand["flags"][n_b:], stream=ks)
+                finally:
+                    g2.capture_end()
+            assert sorted(order) == list(range(n_b)), order
+            cap.comm = g2
+            cs.wait_stream(ks)
         cur.wait_stream(cs)
         self._graphs[sig] = cap
         return cap
-
-    def close(self):
-        """Release what the trainer holds on the device in an order that is safe: drain, drop the captured graphs (their
-        executables are destroyed now, not by the garbage collector at some later HIP-illegal moment), then the library's
-        communicator if the buckets made one.  The trainer is unusable for graph replay afterwards; eager steps still work."""
-        import gc
-        torch.cuda.synchronize()
-        self._graphs.clear()
-        self._eager_seen.clear()
-        gc.collect()
-        torch.cuda.synchronize()
-        self.buckets.close()
 
     @property
     def graph_captured(self) -> bool:

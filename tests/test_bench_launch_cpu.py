@@ -60,7 +60,7 @@ def test_default_launcher_command_is_torch_distributed_run(bench, monkeypatch):
     seen = {}
 
     class R:
-        returncode, stdout = 0, b'{"ok": 1}\n'
+        returncode, stdout, stderr = 0, b'{"ok": 1}\n', b""
 
     def fake_run(cmd, **kw):
         seen["cmd"], seen["env"] = cmd, kw["env"]
@@ -90,6 +90,52 @@ def test_child_exit_code_and_a_missing_line_are_reported(bench, tmp_path, monkey
     assert rc == 7 and json.loads(text)["argv"][1:] == ["--gpus", "2"]
     rc, text = _run(bench, tmp_path, ["--gpus", "2"], 2, monkeypatch, STUB_EXIT="0", STUB_SILENT="1")
     assert rc == 3 and text == ""
+
+
+def test_ranks_that_die_without_a_line_still_leave_one_json_record(bench, tmp_path, monkeypatch):
+    """the first multi-GPU run is one shot.  When the ranks exit non-zero without a result line (a rank other
+    than 0 failed and the launcher took the rest down), the parent writes ONE JSON line with "error" and "stage", built from
+    the per-rank `rank r: stage NAME` / `rank r: FAILED at stage NAME: why` lines the ranks put on stderr."""
+    stub = tmp_path / "dying_launcher.py"
+    stub.write_text(
+        "import sys\n"
+        "sys.stderr.write('rank 0: stage rccl_init done in 1.20 s\\nrank 1: stage rccl_init done in 1.21 s\\n')\n"
+        "sys.stderr.write('rank 0: stage bucket_allreduce 5 buckets ok\\n')\n"
+        "sys.stderr.write('rank 1: FAILED at stage bucket_allreduce: RuntimeError: bucket 2 (9961472 elements): all-reduce checksum\\n')\n"
+        "sys.exit(1)\n")
+    out = tmp_path / "line.json"
+    fd = os.open(str(out), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    try:
+        argv = ["--gpus", "2"]
+        rc = bench.launch_ranks(bench.parse(argv), argv, launcher=[sys.executable, str(stub)], n_visible=2, out_fd=fd)
+    finally:
+        os.close(fd)
+    assert rc == 1
+    lines = out.read_text().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["stage"] == "bucket_allreduce" and d["failed_rank"] == 1
+    assert "checksum" in d["error"] and d["last_stage_per_rank"] == {"0": "bucket_allreduce", "1": "bucket_allreduce"}
+    assert d["metric"] == bench.METRIC and d["returncode"] == 1
+    # no stage line at all (killed before anything ran): the record says so
+    d = bench.failure_record(8, "Killed\n", 137)
+    assert d["stage"] == "launch" and d["failed_rank"] is None and "137" in d["error"]
+
+
+def test_a_rank_that_fails_reports_its_stage_and_rank_zero_prints_the_error_line(monkeypatch, capsys):
+    """Inside a rank: whatever stops it, its stage goes to stderr (`rank r: FAILED at stage S: why`) and rank 0 still prints a JSON
+    line with "error" and "stage" — here the very first thing fails (no GPU in this container)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    assert r.returncode == 1
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["stage"] == "start" and d["failed_rank"] == 0 and "no CPU fallback" in d["error"]
+    assert "rank 0: FAILED at stage start" in r.stderr
 
 
 def test_flag_and_launcher_must_agree_and_no_gpu_is_refused():

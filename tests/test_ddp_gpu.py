@@ -218,11 +218,15 @@ def test_two_ranks_at_the_big_kernels_match_one_process_on_the_global_batch():
 
 def _two_ranks_by_hand(variant, batches, steps, dev):
     """ONE process doing what two ranks do, one after the other: per step, each half's gradient from the same weights
-    (the engine's own forward / fused lm_head + CE / backward, no bucket ever fired), summed, then ONE AdamW step with
+    (the engine's own forward / fused lm_head + CE / backward, no collective ever enqueued), summed, then ONE AdamW step with
     grad_scale 1/2 — DDP's arithmetic (config/config.yaml:45) with nothing concurrent in it.  A rank's gradient is computed by the
     same kernels on the same shapes in both settings and a two-operand sum has one rounding, so the two-rank run must land on
     these bits EXACTLY: a bucket that left before its gradients were final (a deferred grouped weight gradient not joined,
-    the side stream not waited for, the mid-backward segmem trigger raised too early) shows as a mismatch."""
+    the side stream not waited for, the mid-backward segmem trigger raised too early) shows as a mismatch.
+    The deferred weight gradients are joined where the ranks join them — at every bucket boundary — because the grouped
+    launch's split of K depends on what is in the group: one group for the whole backward rounds differently in the last f32
+    bit (1.5e-8 of 2.5e-2, profiles/r06_bucket_bits.txt), and AdamW's first steps turn such a bit into a full +-lr on the
+    weights whose gradient is itself ~1e-8 (m / (sqrt(v) + eps) is a sign there)."""
     from mrmt3 import lib
     from mrmt3.trainer import Trainer
     m = _model(dev, variant)
@@ -241,7 +245,11 @@ def _two_ranks_by_hand(variant, batches, steps, dev):
             loss, dl = lib.lmhead_cross_entropy(dec, eng.W("lm_head"), lab.reshape(-1), want_grad=True,
                                                 grad_dtype=torch.bfloat16)
             flat.G.zero_()
-            eng.backward(tape, dl)
+
+            def layer_done(prefix, i):
+                if tr.buckets.triggered_by(prefix, i):
+                    eng.join_wgrad()
+            eng.backward(tape, dl, on_layer_done=layer_done)
             torch.cuda.synchronize()
             gs.append(flat.G.clone())
             losses.append(float(loss.item()))

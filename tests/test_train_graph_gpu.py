@@ -324,124 +324,126 @@ def test_flag_handoffs_order_two_streams_and_time_out_instead_of_hanging(dev):
     assert int(err.item()) == 1 and out[0].item() == 7.0 and int(seen.item()) == 4
 
 
-def _ran_in_a_process_of_its_own(request) -> bool:
-    """The tests of the captured-collectives forms (MRMT3_DDP_GRAPH, opt-in) run in a child pytest process.  In a fresh process
-    they passed 30 times out of 30 (profiles/tools/r5_session22.sh); at their place near the end of the long-lived suite process —
-    hundreds of graphs, streams and communicators behind it — two suite runs of nine had BOTH captures of the step fail there and
-    the process abort inside the HIP runtime on the eager fallback's device synchronise, taking the whole run with it (an
-    opt-in form's failure must not be able to do that).  Returns True when the test was delegated (and passed)."""
-    import subprocess
-    import sys
-    if os.environ.get("MRMT3_TEST_CHILD") == "1":
-        return False
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", request.node.nodeid, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
-                       cwd=root, env=dict(os.environ, MRMT3_TEST_CHILD="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " passed" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-2000:])
-    return True
-
-
-@pytest.mark.parametrize("mode", ["1", "inline"])
-def test_collectives_captured_in_the_step_equal_the_eager_bucketed_step(dev, monkeypatch, mode, request):
-    """MRMT3_DDP_GRAPH: the gradient buckets' all-reduces captured — "1": as a second graph replayed beside the compute
-    graph on the collective stream, ordered by flag hand-offs; "inline": as nodes of the compute chain.  One rank with the
-    collectives forced through the library's own RCCL communicator (every bucket really goes through mrmt3_allreduce).
-    No graph segment per bucket any more, and losses, weights and AdamW moments equal the EAGER bucketed step bit for bit
-    (DDP's overlap: config/config.yaml:45)."""
-    if _ran_in_a_process_of_its_own(request):
-        return
-    import socket
-    import torch.distributed as dist
-    from mrmt3.trainer import Trainer
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    monkeypatch.setenv("MRMT3_DDP_FORCE_COLLECTIVES", "1")
-    monkeypatch.setenv("MRMT3_DDP_NATIVE", "1")
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        data = _batches(dev, 2, B=8, L=256)
-        runs = {}
-        for captured in (False, True):
-            if captured:
-                monkeypatch.setenv("MRMT3_DDP_GRAPH", mode)
-            else:
-                monkeypatch.delenv("MRMT3_DDP_GRAPH", raising=False)
-            m = _model("t5", dev)
-            tr = Trainer(m, lr=1e-3, graph=captured, layers_per_bucket=2)
-            assert tr.buckets.active and tr.buckets.native and len(tr.buckets.buckets) >= 6
-            losses = [float(tr.train_step(*data[i % 2][:2], audio=True).item()) for i in range(7)]
-            torch.cuda.synchronize()
-            assert tr.graph_captured == captured
-            if captured:
-                cap = next(iter(tr._graphs.values()))
-                assert cap.segments == [] and (cap.comm is not None) == (mode == "1")      # one compute graph (+ one of collectives)
-                assert tr.ddp_graph == mode
-                tr.check_exchange()
-                if mode == "1":
-                    h = tr._hand
-                    n_replays = 7 - tr.graph_warmup
-                    assert h["flags"].tolist() == [n_replays] * (len(tr.buckets.buckets) + 1) == h["seen"].tolist()
-            runs[captured] = (losses, m.flat.P.clone(), m.flat.M.clone(), m.flat.V.clone())
-            tr.buckets.close()
-        assert runs[False][0] == runs[True][0]
-        for a, b in zip(runs[False][1:], runs[True][1:]):
-            assert torch.equal(a, b)
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("why", ["collective_refuses_capture", "streams_share_a_hardware_queue"])
-def test_collectives_that_do_not_capture_fall_back_to_graph_segments(dev, monkeypatch, why, request):
-    """"keep the segmented path as the fallback when capture of a collective fails".  Either the collective
-    is made to refuse a capturing stream, or the trainer's own check says that the compute and the collective stream do not
-    run side by side (one hardware queue for both: the spinning hand-offs would block each other,
-    profiles/r05_two_graph_probe.txt).  The trainer warns, captures one graph per bucket with eager collectives instead,
-    and its weights equal those of a trainer that never tried."""
-    if _ran_in_a_process_of_its_own(request):
-        return
-    import socket
+def test_a_capture_invalidated_half_way_leaves_a_process_that_still_captures(dev, monkeypatch):
+    """Round 6, root cause of the round-5 abort (profiles/r06_capture_abort_root_cause.txt): a capture invalidated half-way
+    (here: the cyclic garbage collector made to run INSIDE it while an older trainer's captured graphs and page-locked tables
+    wait to be freed — exactly what happened near the end of the long-lived GPU suite — and, as a second cause, a device
+    synchronise inside the capture) leaves its stream in capture mode for good on ROCm 7.2 (hipStreamEndCapture does not
+    clear an invalidated capture), a capture_begin on such a stream raises half-way through torch's registrations, and
+    destroying that graph object aborts the process.  The trainer: collects garbage BEFORE the capture and keeps the collector
+    off during it (cause 1 cannot happen: the captured trainer equals the eager one); after a failure takes a FRESH stream;
+    never begins a capture on a stream whose status is not "none".  Everything here runs in THIS process: the trainer with the
+    failed capture goes on eagerly with the right bits, and a new trainer captures and replays right after it."""
+    import gc
     import warnings
-    import torch.distributed as dist
     from mrmt3 import lib
     from mrmt3.trainer import Trainer
+    data = _batches(dev, 2, B=8, L=256)
+
+    def run(sabotage, steps=5):
+        m = _model("t5", dev, dropout_rate=0.0)
+        tr = Trainer(m, lr=1e-3, graph=True)
+        real = m.engine.forward
+        state = {"n": 0}
+
+        def forward(*a, **kw):
+            state["n"] += 1
+            if state["n"] == 3:                              # the capturing step
+                if sabotage == "gc":
+                    gc.collect()                             # (a no-op now: the trainer collected before it began to capture)
+                elif sabotage == "sync":
+                    torch.cuda.synchronize()                 # illegal while the stream is capturing: invalidates the capture
+            return real(*a, **kw)
+        m.engine.forward = forward
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for i in range(steps):
+                tr.train_step(*data[i % 2][:2], audio=True)
+        torch.cuda.synchronize()
+        failed = any("capture of the training step failed" in str(x.message) for x in w)
+        return tr, m, failed
+
+    # an older trainer with captured graphs, dropped WITHOUT close(): garbage in a reference cycle, waiting for the collector
+    old, m_old, _ = run(None)
+    assert old.graph_captured
+    del old, m_old
+    ref_tr, ref_m, failed = run(None)
+    assert not failed and ref_tr.graph_captured
+    # 1. the collector runs inside the capture: nothing left for it to free there, the capture succeeds, same bits
+    tr, m, failed = run("gc")
+    assert not failed and tr.graph_captured
+    assert torch.equal(m.flat.P, ref_m.flat.P)
+    # 2. a capture that IS invalidated: eager from there on, same bits; its stream is abandoned, not reused
+    tr2, m2, failed = run("sync")
+    assert failed and not tr2.use_graph and not tr2.graph_captured and tr2._cap_stream is None
+    assert torch.equal(m2.flat.P, ref_m.flat.P)
+    assert lib.runtime_error_pop() == ""
+    # 3. the process still captures: a new trainer, right away, in the same process
+    tr3, m3, failed = run(None)
+    assert not failed and tr3.graph_captured
+    assert torch.equal(m3.flat.P, ref_m.flat.P)
+    for t in (ref_tr, tr, tr2, tr3):
+        t.close()
+
+
+def test_a_capture_never_begins_on_a_stream_that_is_still_capturing(dev):
+    """The guard itself: `Trainer._capture` asks mrmt3_stream_capture_status before every capture_begin and refuses a stream that
+    is not cleanly out of capture mode with a Python error — torch's own check comes too late (it raises between its two
+    registrations and leaves a graph object whose destructor aborts: profiles/tools/r6_graph_abort_repro.py)."""
+    import warnings
+    from mrmt3 import lib
+    from mrmt3.trainer import Trainer
+    data = _batches(dev, 1, B=4, L=128)
+    m = _model("t5", dev, dropout_rate=0.0)
+    tr = Trainer(m, lr=1e-3, graph=True)
+    tr.train_step(*data[0][:2], audio=True)
+    tr.train_step(*data[0][:2], audio=True)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    assert hip.hipStreamBeginCapture(ctypes.c_void_p(s.cuda_stream), 1) == 0       # hipStreamCaptureModeThreadLocal, no torch state
+    assert lib.stream_capture_status(s) == "active"
+    tr._cap_stream = s                                       # the trainer is handed a stream that is in the middle of a capture
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        loss = tr.train_step(*data[0][:2], audio=True)       # refuses to capture, runs the step eagerly
+    assert any("still in capture mode" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert not tr.use_graph and bool(torch.isfinite(loss).item())
+    assert lib.stream_capture_status(s) == "none"            # _after_failed_capture ended the (valid) capture it found open
+    tr.close()
+
+
+def test_many_trainers_and_communicators_in_one_process_then_a_capture(dev, monkeypatch):
+    """an in-process repeat — trainers with graphs and communicators of the library's own created and released many
+    times over (every second one through close(), the others simply dropped), then one more trainer captures and replays and
+    lands on the bits of the first.  The long-lived-process condition the round-5 suite could only meet by accident."""
+    import socket
+    import torch.distributed as dist
+    from mrmt3.trainer import Trainer
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     monkeypatch.setenv("MRMT3_DDP_FORCE_COLLECTIVES", "1")
     monkeypatch.setenv("MRMT3_DDP_NATIVE", "1")
-    real = lib.Comm.allreduce
-
-    def refusing(self, t, average=False, stream=None):
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("allreduce: this communicator does not capture")
-        return real(self, t, average=average, stream=stream)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
-        data = _batches(dev, 2, B=8, L=256)
-        runs = {}
-        for sabotage in (False, True):
-            if sabotage:
-                monkeypatch.setenv("MRMT3_DDP_GRAPH", "1")
-                if why == "collective_refuses_capture":
-                    monkeypatch.setattr(lib.Comm, "allreduce", refusing)
-                else:
-                    monkeypatch.setattr(Trainer, "_side_by_side", lambda self, a, b: False)
-            m = _model("t5", dev)
+        data = _batches(dev, 2, B=4, L=128)
+        first = None
+        for it in range(12):
+            m = _model("t5", dev, dropout_rate=0.0)
             tr = Trainer(m, lr=1e-3, graph=True, layers_per_bucket=2)
-            with warnings.catch_warnings(record=True) as w:
-                warnings.simplefilter("always")
-                for i in range(6):
-                    tr.train_step(*data[i % 2][:2], audio=True)
+            for i in range(4):
+                tr.train_step(*data[i % 2][:2], audio=True)
             torch.cuda.synchronize()
-            cap = next(iter(tr._graphs.values()))
-            assert tr.graph_captured and cap.comm is None and len(cap.segments) == len(tr.buckets.buckets)
-            if sabotage:
-                assert tr.ddp_graph == "" and any("falling back to one graph per bucket" in str(x.message) for x in w)
-            runs[sabotage] = (m.flat.P.clone(), m.flat.M.clone())
-            tr.buckets.close()
-        assert torch.equal(runs[False][0], runs[True][0]) and torch.equal(runs[False][1], runs[True][1])
+            assert tr.graph_captured and tr.buckets._comm is not None
+            assert len(next(iter(tr._graphs.values())).segments) == len(tr.buckets.buckets)
+            if first is None:
+                first = m.flat.P.clone()
+            assert torch.equal(m.flat.P, first), it
+            if it % 2 == 0:
+                tr.close()
+            del tr, m
     finally:
         dist.destroy_process_group()
