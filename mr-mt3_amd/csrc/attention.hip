@@ -134,13 +134,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
     for (int qt = 0; qt < RT; ++qt) {
       if (__builtin_expect(need_mask, 0)) {
+        // one limit per query row (the last key it may see) and ONE compare per element against it: written as
+        // `key >= Lk || (causal && key > q)` the sixteen `key >= Lk` tests are common to both query tiles, hipcc kept their
+        // results in SGPR pairs across the tiles and spilled 68 SGPRs to VGPR lanes in <true, true, 2>
+        const int lim = P.causal ? min(P.Lk - 1, qrow[qt]) : P.Lk - 1;
+        const int key0 = kv0 + fg * 4;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kv0 + kt * 16 + fg * 4 + r;
-            if (key >= P.Lk || (P.causal && key > qrow[qt])) sT[qt][kt][r] = -INFINITY;
-          }
+          for (int r = 0; r < 4; ++r)
+            if (key0 + kt * 16 + r > lim) sT[qt][kt][r] = -INFINITY;
       }
       float mloc = -INFINITY;
 #pragma unroll
@@ -452,6 +455,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
     if (pass == 1) __syncthreads();
   }
   const int q0 = q_tile * (64 * RT);
+  // (per pass, the lane's coordinates are re-derived from an opaque copy of the lane id: everything that depends only on the
+  // lane is otherwise hoisted out of the pass loop and held across both passes in registers of its own — at the 168 registers
+  // three workgroups per CU allow, hipcc spilled four of them: 20 B of scratch in <true, true, 2>)
+  int lane_p = lane;
+  asm volatile("" : "+v"(lane_p));
+  const int fr = lane_p & 15, fg = lane_p >> 4, fq = fr >> 2, fp = lane_p & 3;
 
   bf16x8 qf[RT][2], dof[RT][2];
   int qrow[RT];
@@ -568,10 +577,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams P) {
     }
   }
   VMCNT(0);
+  // (the lane's first row goes through an opaque move and the rows are re-derived from it: hipcc otherwise keeps the
+  // prologue's qrow[] / row pointers alive across the key loop in registers of their own — at the 168 registers three
+  // workgroups per CU allow, those were what it spilled: 4 VGPRs / 20 B of scratch in <true, true, 2>)
+  int row0 = q0 + uw * (16 * RT) + fr;
+  asm volatile("" : "+v"(row0));
 #pragma unroll
   for (int qt = 0; qt < RT; ++qt) {
-    if (qrow[qt] >= P.Lq) continue;
-    bf16_t* row = P.dq + ((size_t)b * P.Lq + qrow[qt]) * P.lddq + h * HD;
+    const int qr = row0 + qt * 16;
+    if (qr >= P.Lq) continue;
+    bf16_t* row = P.dq + ((size_t)b * P.Lq + qr) * P.lddq + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 a = dqT[qt][dt];

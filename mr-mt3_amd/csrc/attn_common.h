@@ -16,10 +16,8 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
-  bf16x8 r;
-  r[0] = (short)f2bf(lo[0]); r[1] = (short)f2bf(lo[1]); r[2] = (short)f2bf(lo[2]); r[3] = (short)f2bf(lo[3]);
-  r[4] = (short)f2bf(hi[0]); r[5] = (short)f2bf(hi[1]); r[6] = (short)f2bf(hi[2]); r[7] = (short)f2bf(hi[3]);
-  return r;
+  const u32x4 r = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3])};
+  return __builtin_bit_cast(bf16x8, r);      // four v_cvt_pk_bf16_f32 (pairs), nothing to join
 }
 
 // attention-probability dropout.  Element (q,k) of head-matrix bh takes byte (k & 3) of the 32-bit word

@@ -123,9 +123,11 @@ extern "C" int mrmt3_allreduce(void* comm, void* buf, size_t count, int dtype, i
   return MRMT3_OK;
 }
 
-// ---- hand-offs between two replayed graphs --------------------------------------------------------------------------------
-// The data-parallel step as TWO hipGraphs on two streams (mrmt3/trainer.py, MRMT3_DDP_GRAPH=1): the compute chain and the
-// chain of the gradient buckets' all-reduces.  Each is captured as ONE linear chain (ROCm 7.2 maps forked graphs badly: a
+// ---- counting hand-offs between two streams ---------------------------------------------------------------------------------
+// In the product: the probe that tells whether two streams run side by side (Trainer._pick_collective_stream: a wait on one,
+// its signal on the other; on a shared hardware queue the wait times out).  Built in round 5 for the data-parallel step as TWO
+// hipGraphs on two streams (measured, lost, removed in round 6: profiles/tools/closed/trainer_captured_collectives_r5.py): the
+// compute chain and the chain of the gradient buckets' all-reduces.  Each is captured as ONE linear chain (ROCm 7.2 maps forked graphs badly: a
 // graph with a side branch replayed in 40.9 instead of 25 ms), and what one graph has to tell the other —
 // "bucket i is complete", "every bucket is reduced" — goes through counting flags in device memory instead of events:
 // an event-wait node waits for whatever record is the latest when it RUNS, which for two graphs replayed side by side may

@@ -75,8 +75,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+// a PAIR in one v_cvt_pk_bf16_f32 (the vector convert); converting the halves apart and joining them compiled to two
+// conversions + a shift + an or (round 6, seen in the epilogue of profiles/tools/gemm_w4_probe.hip).  Same bits.
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 // ---- wave / block reductions (wave = 64) -----------------------------------------------------------

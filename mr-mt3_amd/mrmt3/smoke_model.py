@@ -11,8 +11,10 @@ def run():
     from mrmt3.synthetic import T5_SMALL, golden_weights, synth_mel, synth_labels
     from oracle import t5_ref
     dev = torch.device("cuda:0")
-    mel = torch.from_numpy(synth_mel(1))
-    lab = torch.from_numpy(synth_labels(1, full=False, seed=777))
+    # two segments with full-length (1024-token) labels: the inputs of tests/test_model_gpu.py's "full" case, for which the
+    # reference's own bf16-autocast run was recorded (tests/golden/bf16_bound.npz, make_golden.py --bf16-bound)
+    mel = torch.from_numpy(synth_mel(2))
+    lab = torch.from_numpy(synth_labels(2, full=True))
     sd = {k: torch.from_numpy(v) for k, v in golden_weights(T5_SMALL).items()}
     with torch.no_grad():
         ref = t5_ref.forward_logits(sd, T5_SMALL, mel, lab)
@@ -21,10 +23,31 @@ def run():
     logits = model(inputs=mel.to(dev), labels=lab.to(dev))
     loss = torch.nn.functional.cross_entropy(logits.view(-1, logits.shape[-1]), lab.to(dev).view(-1), ignore_index=-100)
     loss.backward()
-    err = (logits.detach().cpu() - ref).abs().max().item()
     gnorm = model.flat.G.norm().item()
-    assert abs(loss.item() - ref_loss) < 2e-3 and err < 5e-2 and np.isfinite(gnorm) and gnorm > 0, (loss.item(), ref_loss, err, gnorm)
-    print("smoke: bf16 fwd+bwd loss %.5f (oracle %.5f) max|dlogit| %.3e |grad| %.3e" % (loss.item(), ref_loss, err, gnorm))
+    # the bench-shape rule (tests/test_bench_shape_gpu.py): loss within north_star's 1e-3 of the fp32 oracle; logits no further
+    # from fp32 than the reference's own run under torch.autocast(bfloat16) on these inputs, at the 4096 logit positions that run
+    # was recorded at (max 3.97e-2, rel-L2 7.77e-3 — 1e-3 absolute on O(10) logits is not reachable with bf16 operands by
+    # anyone, the reference included).  The fixtures are data files of the repo; without them the constants below stand.
+    import os
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+    bound_max, bound_rel = 0.039708376, 0.0077730296
+    got, want = logits.detach().cpu().reshape(-1).double(), ref.reshape(-1).double()
+    try:
+        idx = torch.from_numpy(np.load(os.path.join(gold, "model_golden.npz"))["t5.full.logit_idx"]).long()
+        b = np.load(os.path.join(gold, "bf16_bound.npz"))
+        bound_max, bound_rel = float(b["t5.full.autocast_max_abs"]), float(b["t5.full.autocast_rel_l2"])
+        got, want = got[idx], want[idx]
+    except Exception:
+        bound_max *= 1.5                       # every logit instead of the recorded sample: allow for the larger population
+    d = got - want
+    err, rel = d.abs().max().item(), (d.norm() / want.norm()).item()
+    assert abs(loss.item() - ref_loss) < 1e-3, (loss.item(), ref_loss)
+    assert err <= bound_max and rel <= bound_rel, (err, bound_max, rel, bound_rel)
+    assert np.isfinite(gnorm) and gnorm > 0, gnorm
+    print("smoke: bf16 fwd+bwd, 2 segments x 1024 tokens: loss %.5f (oracle %.5f, |d| %.1e < 1e-3); logits max|d| %.3e <= %.3e, "
+          "rel-L2 %.2e <= %.2e (the reference's own bf16-autocast run); |grad| %.3e"
+          % (loss.item(), ref_loss, abs(loss.item() - ref_loss), err, bound_max, rel, bound_rel, gnorm))
+    mel = mel[:1]
     m32 = T5ForConditionalGeneration(T5_SMALL, compute_dtype=torch.float32).load_golden().to(dev).eval()
     ids = m32.generate(mel.to(dev), max_length=16).cpu()
     with torch.no_grad():

@@ -77,9 +77,8 @@ def pytest_sessionfinish(session, exitstatus):
     """Orderly teardown while the interpreter and the HIP runtime are still whole: drain the device, then collect what the tests
     left behind NOW — captured hipGraphs, page-locked plan tables (`mrmt3_host_free` in `_PinnedTable.__del__`), RCCL communicators
     whose owner went away (`lib.Comm`'s finalizer) — instead of during interpreter shutdown, where the order in which torch, HIP
-    and RCCL unload is not ours to choose.  (Added while hunting two aborted suite runs of this round; those turned out to die
-    INSIDE a test of the opt-in captured-collectives forms — tests/test_train_graph_gpu.py now runs them in a child process — but
-    an orderly exit is worth having either way.)"""
+    and RCCL unload is not ours to choose.  (Added in round 5 while hunting two aborted suite runs; round 6 found their cause — the collector freeing such objects INSIDE a
+    capture, profiles/r06_capture_abort_root_cause.txt — and fixed it in the trainer; an orderly exit is worth having either way.)"""
     import gc
     try:
         import torch
