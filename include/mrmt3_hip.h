@@ -468,11 +468,18 @@ int mrmt3_flag_wait(const int32_t* flag, int32_t* seen, int32_t* err, int timeou
  *                                  writes its name to text[0..n).  A launch wrapper of this library reports whatever is in
  *                                  that slot as ITS launch failure, so a host that has just survived a failed HIP call of
  *                                  its own (a refused capture, an RCCL error) empties the slot before launching again.
+ *   mrmt3_stream_create / _destroy : a non-blocking stream of the caller's own (priority as hipStreamCreateWithPriority),
+ *                                  outside every framework's stream pool: torch's `Stream()` comes round robin out of a pool of 32
+ *                                  per priority, and ROCm 7.2 never takes an INVALIDATED stream out of capture mode, so a stream
+ *                                  poisoned by one failed capture would come back to a later one.  Destroy only when nothing
+ *                                  enqueued on it is pending and no graph is being captured on it.
  *   mrmt3_abort_trace_install    : opt-in diagnostics — on SIGABRT / SIGSEGV write the native frames of the faulting thread to
  *                                  `path` (NULL or "": stderr), then hand the signal to the previous handler. */
 int mrmt3_stream_capture_status(void* stream);
 int mrmt3_stream_abandon_capture(void* stream);
 int mrmt3_runtime_error_pop(char* text, int n);
+int mrmt3_stream_create(void** stream_out, int priority);
+int mrmt3_stream_destroy(void* stream);
 int mrmt3_abort_trace_install(const char* path);
 
 #ifdef __cplusplus

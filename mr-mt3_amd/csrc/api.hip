@@ -100,7 +100,7 @@ extern "C" int mrmt3_reset_knobs(void) {
   return MRMT3_OK;
 }
 
-extern "C" int mrmt3_version(void) { return 109; /* 0.1.9: round 6 (capture hygiene entry points, abort trace); 108: round 5 (knobs read once per process + mrmt3_set_knob; kernel diagnostics only in the -DMRMT3_DIAG build); 107: round 4 */ }
+extern "C" int mrmt3_version(void) { return 110; /* 0.1.10: round 6 (capture hygiene entry points, owned streams, abort trace, pair bf16 conversion); 108: round 5 (knobs read once per process + mrmt3_set_knob; kernel diagnostics only in the -DMRMT3_DIAG build); 107: round 4 */ }
 extern "C" const char* mrmt3_last_error(void) { return g_err; }
 
 // Page-locked host memory for tables the device reads through an async copy (the grouped weight-gradient plan): owned by
@@ -160,6 +160,28 @@ extern "C" int mrmt3_stream_abandon_capture(void* stream) {
   }
   (void)hipGetLastError();
   return before;
+}
+
+// A stream of the caller's own, outside every framework's stream pool: torch hands `torch.cuda.Stream()` out of a pool of 32
+// per priority, round robin — a stream that a failed capture left invalidated for good comes BACK from that pool some
+// dozens of streams later (seen in round 6: a fresh trainer's "new" capture stream was born invalidated).  The capture stream
+// of the trainer is therefore created and destroyed here.
+extern "C" int mrmt3_stream_create(void** stream_out, int priority) {
+  MR_CHECK_ARG(stream_out != nullptr, "stream_create: null pointer");
+  hipStream_t s = nullptr;
+  MR_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+  *stream_out = (void*)s;
+  return MRMT3_OK;
+}
+extern "C" int mrmt3_stream_destroy(void* stream) {
+  if (stream == nullptr) return MRMT3_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    mrmt3_set_error("stream_destroy: %s", hipGetErrorString(e));
+    return MRMT3_ERR_HIP;
+  }
+  return MRMT3_OK;
 }
 
 extern "C" int mrmt3_runtime_error_pop(char* text, int n) {

@@ -94,6 +94,8 @@ _SIGS = {
     "mrmt3_stream_capture_status": (ci, [vp]),
     "mrmt3_stream_abandon_capture": (ci, [vp]),
     "mrmt3_runtime_error_pop": (ci, [C.c_char_p, ci]),
+    "mrmt3_stream_create": (ci, [C.POINTER(vp), ci]),
+    "mrmt3_stream_destroy": (ci, [vp]),
     "mrmt3_abort_trace_install": (ci, [C.c_char_p]),
 }
 
@@ -139,7 +141,7 @@ def load():
     return lib
 
 
-MIN_VERSION = 109
+MIN_VERSION = 110
 COUNTER_NAMES = ("gemm_nt_tile", "gemm_nt8", "gemm_nt_geglu", "tn_group", "tn8", "tn_tile", "attn_fwd", "attn_bwd",
                  "attn_bwd_onepass", "attn_f32", "tn_f32", "gemm_nt_splitk", "gemm_nt_addnorm", "gemm_nt_normbwd",
                  "gemm_nt_geglubwd")
@@ -1042,3 +1044,29 @@ def runtime_error_pop() -> str:
 def abort_trace_install(path: str = "") -> None:
     """Opt-in: native frames of the faulting thread on SIGABRT / SIGSEGV (to `path`, default stderr)."""
     _check(load().mrmt3_abort_trace_install(path.encode() if path else None), "abort_trace_install")
+
+
+class OwnedStream:
+    """A HIP stream of our own (mrmt3_stream_create), wrapped for torch as an ExternalStream: NOT from torch's pool of 32 streams
+    per priority, which hands a stream that a failed capture left invalidated back out a few dozen `Stream()` calls later.
+    `.stream` is the torch handle; close() destroys the HIP stream (call it only when nothing on it is pending)."""
+
+    def __init__(self, device=None, priority: int = 0):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = vp()
+        with torch.cuda.device(dev):
+            _check(load().mrmt3_stream_create(C.byref(h), int(priority)), "stream_create")
+        self.handle, self.device = h.value, dev
+        self.stream = torch.cuda.ExternalStream(self.handle, device=dev)
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h and _lib is not None:
+            self.stream = None
+            _lib.mrmt3_stream_destroy(vp(h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -112,6 +112,7 @@ class Trainer:
         self._graphs = {}                # signature -> _CapturedStep
         self._eager_seen = {}
         self._cap_stream = None
+        self._cap_owner = None
 
     def mel_from_audio(self, audio):
         """[B, n_samples] f32 device audio -> [B, frames, 512] mel in the compute dtype."""
@@ -236,6 +237,16 @@ class Trainer:
                 uniq[k] = v
         return uniq
 
+    def _drop_capture_stream(self):
+        """Forget the capture stream; if it is one of our own, destroy it (an invalidated stream is lost for capturing)."""
+        owner, self._cap_owner, self._cap_stream = getattr(self, "_cap_owner", None), None, None
+        if owner is not None:
+            try:
+                torch.cuda.synchronize()
+            except RuntimeError:
+                pass
+            owner.close()
+
     def _after_failed_capture(self, exc) -> str:
         """Called with the exception of a capture that failed, BEFORE anything else is launched or synchronised.  Ends the
         capture on every stream that is still in capture mode (an exception between capture_begin and capture_end — or a
@@ -254,7 +265,7 @@ class Trainer:
         pending = lib.runtime_error_pop()
         if pending:
             left.append("pending HIP error %s" % pending)
-        self._cap_stream = None                              # a later capture (another input shape) gets a fresh stream
+        self._drop_capture_stream()                          # a later capture (another input shape) gets a fresh stream
         self.engine.reset_deferred()
         self.engine._stream_ctr = 0
         log = os.environ.get("MRMT3_CAPTURE_LOG")
@@ -314,7 +325,10 @@ class Trainer:
         eng = self.engine
         cur = torch.cuda.current_stream()
         if self._cap_stream is None:
-            self._cap_stream = torch.cuda.Stream()
+            # a stream of our own, not one out of torch's pool: a stream that some failed capture left invalidated comes back
+            # from that pool (round robin over 32), and ROCm never takes it out of capture mode again
+            self._cap_owner = lib.OwnedStream(inputs.device)
+            self._cap_stream = self._cap_owner.stream
         cs = self._cap_stream
         st = lib.stream_capture_status(cs)
         if st != "none":                   # (checked again before every segment's capture_begin: see begin())
@@ -404,6 +418,7 @@ class Trainer:
         self._eager_seen.clear()
         gc.collect()
         torch.cuda.synchronize()
+        self._drop_capture_stream()
         self.buckets.close()
 
     @property
