@@ -494,6 +494,24 @@ def test_bench_spawns_its_ranks_through_the_launcher(dev):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["launched_by"].startswith("bench.py --gpus 1 -> child")
     assert d["collectives"].startswith("rccl") and d["value"] > 0 and d["steps"] == 3
+    # the multi-rank preflight ran: every stage left its line on stderr and its figures in the record
+    for st in ("rccl_init", "bucket_allreduce", "stream_pick", "capture", "timed", "report"):
+        assert "rank 0: stage %s" % st in r.stderr, (st, r.stderr[-1500:])
+    pre = d["preflight"]
+    assert len(pre["bucket_allreduce"]) == 5 and all(b["ms"] > 0 for b in pre["bucket_allreduce"])
+    assert pre["capture"]["captured"] and pre["capture"]["graph_segments"] == 6 and pre["capture"]["replicas_identical"]
+    assert pre["stream_pick"]["seconds"] < 1.5 and pre["rccl_init_seconds"] > 0
+    # a rank that dies: its stage on stderr, ONE JSON line with "error" and "stage", exit code 1
+    env_bad = dict(env, MRMT3_DDP_LAYERS_PER_BUCKET="not-a-number")
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--batch", "4", "--steps", "1",
+                        "--warmup", "0", "--extra-batch", "0", "--no-inference", "--no-cpu-baseline", "--no-roofline"],
+                       capture_output=True, text=True, env=env_bad, timeout=600)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    e = json.loads(lines[0])
+    assert e["value"] is None and e["stage"] == "model" and "ValueError" in e["error"], e
+    assert "rank 0: FAILED at stage model" in r.stderr
     # more ranks than GPUs on this box: refused, nothing on stdout
     n = torch.cuda.device_count()
     r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True,
