@@ -458,7 +458,7 @@ def inference_rtf(dev, tokens, batch):
     return out
 
 
-PMC_TABLES = ("r05_pmc_step_traffic.json", "r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json")
+PMC_TABLES = ("r06_pmc_step_traffic.json", "r05_pmc_step_traffic.json", "r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json")
 
 
 def pmc_table(batch, lib_version):
