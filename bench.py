@@ -689,7 +689,11 @@ def run(args, world, rank, local, json_fd):
                                    "kernels on one stream exactly as the replayed graph runs them (the timed steps "
                                    "themselves are graph replays: events cannot be placed inside); the 16 wi projections "
                                    "(GEMM + gated-GELU epilogue in one launch) are their own family gemm_nt_geglu_bf16, "
-                                   "priced at the GEMM's FLOPs; gemm_tn_bf16 = the grouped weight-gradient launch + its reduce",
+                                   "priced at the GEMM's FLOPs; gemm_tn_bf16 = the grouped weight-gradient launch + its reduce.  "
+                                   "What bounds the family (round 6, profiles/r06_gemm_hidden_stores.txt): a 256 x 256 x 512 tile moves "
+                                   "512 KB in and 128 KB out through its CU's vector-memory path in ~15 us (additive) against 8 us of "
+                                   "MFMA: these short-K bf16-output products sit at ~0.35 of the MFMA peak for that reason, with a "
+                                   "ping-pong schedule and with a one-wave-per-SIMD schedule with trickled stores alike",
                            "families_ms_per_step": {k: v["ms"] / n_rf for k, v in fam.items() if "@" not in k},
                            # attn_*: priced at the FULL score square, as the reference computes it;
                            # attn_*@executed: the FLOPs the kernels issue (causal key tiles above the diagonal skipped)

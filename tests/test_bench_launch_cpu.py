@@ -125,11 +125,11 @@ def test_ranks_that_die_without_a_line_still_leave_one_json_record(bench, tmp_pa
 def test_a_rank_that_fails_reports_its_stage_and_rank_zero_prints_the_error_line(monkeypatch, capsys):
     """Inside a rank: whatever stops it, its stage goes to stderr (`rank r: FAILED at stage S: why`) and rank 0 still prints a JSON
     line with "error" and "stage" — here the very first thing fails (no GPU in this container)."""
-    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
     import torch
     if torch.cuda.is_available():
-        pytest.skip("needs a box without a GPU")
+        pytest.skip("needs a box without a GPU (with one, the rank would go on to a rendezvous nobody answers)")
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
     assert r.returncode == 1
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
