@@ -19,26 +19,32 @@
 // dQ of the previous one) in OPPOSITE order inside a barrier interval, the cheapest form of a half-block stagger: 155 -> 176-181 us
 // per cross-attention site, +0.2 ms per step, profiles/r05_onepass_stagger_ab.txt.  MFMA and VALU instructions do not overlap on
 // a gfx950 SIMD, so there is nothing for a stagger to overlap; what it adds is 20 VGPRs and a second copy of the loop.)
+#include <type_traits>
+
 #include "attn_common.h"
 
-#define OP_LK 256
 #define OP_STAGES 4
 #define OP_STAGE_BYTES (4 * 4096 + 256)        // Q | dO | O | O_lo tiles of 32 rows x 128 B, then lse[32] (twice)
-#define OP_K_BYTES (OP_LK * 128)
-#define OP_X_BYTES (OP_LK * 64)                // dS exchange: [key][32 queries] bf16, 8-byte chunks swizzled by the key
-#define OP_LDS_BYTES (OP_K_BYTES + 2 * OP_X_BYTES + OP_STAGES * OP_STAGE_BYTES + 2 * 32 * 4)
+// key capacity of a workgroup: NT = 2 key tiles of 16 per wave -> 256 keys; NT = 3 -> 320 keys = 20 tiles, dealt 3 + 2 over the
+// two waves of a SIMD (waves w and w + 4), so every SIMD carries 5 tiles (MR-MT3's own model: 256 encoder frames + 64 memory slots,
+// models/t5_segmem_v2_with_prev.py:125-128)
+#define OP_LKMAX(NT) ((NT) == 2 ? 256 : 320)
+#define OP_K_BYTES(NT) (OP_LKMAX(NT) * 128)
+#define OP_X_BYTES(NT) (OP_LKMAX(NT) * 64)     // dS exchange: [key][32 queries] bf16, 8-byte chunks swizzled by the key
+#define OP_LDS_BYTES(NT) (OP_K_BYTES(NT) + 2 * OP_X_BYTES(NT) + OP_STAGES * OP_STAGE_BYTES + 2 * 32 * 4)
 
 // exchange buffer swizzle: 8-byte chunk c (4 queries) of key row r sits at chunk c ^ xsw(r).  Rows r, r+4, r+8, r+12 —
 // one bank group apart at the 64-byte pitch — get four different chunk shifts, so the 8-byte writes of 16 consecutive
 // keys and the transposed reads of rows 4g..4g+3 are both conflict-free.
 __device__ __forceinline__ int xsw(int row) { return (((row >> 2) & 1) << 2) ^ (((row >> 3) & 1) << 1); }
 
-template <bool DROP>
+template <bool DROP, int NT = 2>
 __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnParams P) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[OP_LDS_BYTES];
+  constexpr int LKMAX = OP_LKMAX(NT);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[OP_LDS_BYTES(NT)];
   unsigned char* const ldsK = lds;
-  unsigned char* const ldsX = lds + OP_K_BYTES;
-  unsigned char* const ldsS = ldsX + 2 * OP_X_BYTES;
+  unsigned char* const ldsX = lds + OP_K_BYTES(NT);
+  unsigned char* const ldsS = ldsX + 2 * OP_X_BYTES(NT);
   float* const ldsD = (float*)(ldsS + OP_STAGES * OP_STAGE_BYTES);      // delta[2][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int uw = __builtin_amdgcn_readfirstlane(wave);
@@ -48,39 +54,45 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnParams P) 
   const bf16_t* dob = P.d_o + (size_t)b * P.Lq * P.lddo + h * HD;
   const bf16_t* ob = P.o + (size_t)b * P.Lq * P.ldo + h * HD;
   const bf16_t* olb = P.o_lo_in ? P.o_lo_in + (size_t)b * P.Lq * P.ldo + h * HD : ob;
-  const bf16_t* kb = P.k + (size_t)b * OP_LK * P.ldk + h * HD;
-  const bf16_t* vb = P.v + (size_t)b * OP_LK * P.ldv + h * HD;
+  const bf16_t* kb = P.k + (size_t)b * P.Lk * P.ldk + h * HD;
+  const bf16_t* vb = P.v + (size_t)b * P.Lk * P.ldv + h * HD;
   const float* lse = P.lse + ((size_t)b * P.H + h) * P.Lq;
   const unsigned drop_bh = P.drop.seed + step_salt(P.drop.step) + (unsigned)(b * P.H + h) * DROP_CB;
   const __amdgpu_buffer_rsrc_t qres = rows_rsrc(qb, P.Lq, P.ldq), dores = rows_rsrc(dob, P.Lq, P.lddo);
   const __amdgpu_buffer_rsrc_t ores = rows_rsrc(ob, P.Lq, P.ldo), olres = rows_rsrc(olb, P.Lq, P.ldo);
-  const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, OP_LK, P.ldk);
+  const __amdgpu_buffer_rsrc_t kres = rows_rsrc(kb, P.Lk, P.ldk);        // rows past Lk read as zeros
   const unsigned q_lane = rows8_lane_off(P.ldq, lane), do_lane = rows8_lane_off(P.lddo, lane);
   const unsigned o_lane = rows8_lane_off(P.ldo, lane), k_lane = rows8_lane_off(P.ldk, lane);
   const bool have_lo = P.o_lo_in != nullptr;
 
-  // K image of the whole head -> LDS (phase C's A operand), 32 rows per wave
+  // K image of the whole head -> LDS (phase C's A operand), LKMAX / 8 rows per wave
+  constexpr int KPIECES = LKMAX / 64;                       // 8-row pieces per wave
 #pragma unroll
-  for (int i = 0; i < 4; ++i) blds_rows8(kres, k_lane, ((uw * 4 + i) * 8) * P.ldk * 2, ldsK + (uw * 4 + i) * 1024);
+  for (int i = 0; i < KPIECES; ++i) blds_rows8(kres, k_lane, ((uw * KPIECES + i) * 8) * P.ldk * 2, ldsK + (uw * KPIECES + i) * 1024);
 
-  // this wave's 32 keys: K and V fragments (B operands of S = Q K^T and dP = dO V^T) for the whole kernel
-  bf16x8 kf[2][2], vf[2][2];
-  int key[2];
-  unsigned drop_k[2];
+  // this wave's key tiles: K and V fragments (B operands of S = Q K^T and dP = dO V^T) for the whole kernel.
+  // NT = 2: tiles 2w, 2w + 1.  NT = 3: waves 0-3 own tiles 5w .. 5w + 2, waves 4-7 tiles 5(w - 4) + 3, + 4 (their third slot is idle:
+  // every piece of work on tile slot 2 sits behind the wave-uniform test `nt < my_nt`).
+  const int my_nt = NT == 2 ? 2 : (uw < 4 ? 3 : 2);
+  const int tile0 = NT == 2 ? 2 * uw : (uw < 4 ? 5 * uw : 5 * (uw - 4) + 3);
+  bf16x8 kf[NT][2], vf[NT][2];
+  int key[NT];
+  unsigned drop_k[NT];
   const unsigned drop_bmask = 0xFFu << (8 * fp), drop_bthr = P.drop.thresh8 << (8 * fp);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    key[nt] = uw * 32 + nt * 16 + fr;
+  for (int nt = 0; nt < NT; ++nt) {
+    key[nt] = (tile0 + nt) * 16 + fr;
     drop_k[nt] = drop_bh + ((unsigned)key[nt] >> 2) * DROP_CK + (unsigned)(fg * 4 + fp) * DROP_CQ;
+    const bool live = NT == 2 || (nt < my_nt && key[nt] < P.Lk);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      kf[nt][ks] = *(const bf16x8*)(kb + (size_t)key[nt] * P.ldk + ks * 32 + fg * 8);
-      vf[nt][ks] = *(const bf16x8*)(vb + (size_t)key[nt] * P.ldv + ks * 32 + fg * 8);
+      if (NT == 2) kf[nt][ks] = *(const bf16x8*)(kb + (size_t)key[nt] * P.ldk + ks * 32 + fg * 8);     // (NT = 3: from the LDS image)
+      vf[nt][ks] = live ? *(const bf16x8*)(vb + (size_t)key[nt] * P.ldv + ks * 32 + fg * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  f32x4 dkT[2][4], dvT[2][4];
+  f32x4 dkT[NT][4], dvT[NT][4];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dkT[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -125,10 +137,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnParams P) 
   // phase C: dQ^T tile (dt = wave & 3, qt = wave >> 2) of the block whose dS sits in exchange buffer `xb`
   const int c_dt = uw & 3, c_qt = uw >> 2;
   auto dq_of = [&](int xb, int qb0) {
-    const unsigned char* X = ldsX + xb * OP_X_BYTES;
+    const unsigned char* X = ldsX + xb * OP_X_BYTES(NT);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // (NT = 3: the lane's coordinates from an opaque copy of the lane id — the ten per-step read addresses below are otherwise
+    // hoisted out of the block loop and held in ten registers of their own, which the 320-key form does not have: re-derived
+    // here they are ONE base each plus immediate offsets)
+    int lane_c = lane;
+    if (NT == 3) asm volatile("" : "+v"(lane_c));
+    const int fr = lane_c & 15, fg = lane_c >> 4, fq = fr >> 2, fp = lane_c & 3;
 #pragma unroll
-    for (int ks = 0; ks < OP_LK / 32; ++ks) {
+    for (int ks = 0; ks < LKMAX / 32; ++ks) {
       const bf16x8 kt_ = lds_tr8(ldsK, ks * 32 + fg * 4 + fq, c_dt * 2 + (fp >> 1), (fp & 1) * 8);
       const int row = ks * 32 + fg * 4 + fq;
       const unsigned char* a = X + row * 64 + (((c_qt * 4 + fp) ^ xsw(row)) << 3);
@@ -158,69 +176,98 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnParams P) 
     const float* ldlt = ldsD + (it & 1) * 32;
     const int nxt = cur == OP_STAGES - 1 ? 0 : cur + 1;
     const bool need_mask = qb0 + 32 > P.Lq;
-    bf16x8 pdB[2], dsB[2];
-    f32x4 pd[2][2], ds[2][2];  // [qt][nt]
+    unsigned char* X = ldsX + (it & 1) * OP_X_BYTES(NT);
+    // phase A for the key-tile slots [N0, N0 + CNT) of this wave.  NT = 2: one call for both tiles (the kernel of round 3).
+    // NT = 3: slots 0-1, then — waves 0-3 only, a wave-uniform branch — slot 2 in a pass of its own, so that the temporaries of
+    // one pass are dead before the other starts: with all three tiles in one pass the kernel needs ~300 registers and spills 143.
+    // The K fragments of the NT = 3 form come from the K image in LDS (it is there for phase C anyway), not from registers.
+    auto phase_a = [&](auto n0_tag, auto cnt_tag) __attribute__((always_inline)) {
+      constexpr int N0 = decltype(n0_tag)::value, CNT = decltype(cnt_tag)::value;
+      bf16x8 pdB[CNT], dsB[CNT];
+      f32x4 pd[2][CNT], ds[2][CNT];  // [qt][nt]
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const bf16x8 qa0 = lds_row8(lq, qt * 16 + fr, fg), qa1 = lds_row8(lq, qt * 16 + fr, 4 + fg);
-      const bf16x8 da0 = lds_row8(ldo_, qt * 16 + fr, fg), da1 = lds_row8(ldo_, qt * 16 + fr, 4 + fg);
-      float lrow[4], drow[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        lrow[r] = lstat[qt * 16 + fg * 4 + r] * LOG2E;
-        drow[r] = ldlt[qt * 16 + fg * 4 + r];
-      }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = mfma16(qa0, kf[nt][0], s);
-        s = mfma16(qa1, kf[nt][1], s);
-        dp = mfma16(da0, vf[nt][0], dp);
-        dp = mfma16(da1, vf[nt][1], dp);
-        float pv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lrow[r]));
-        if (__builtin_expect(need_mask, 0)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (qb0 + qt * 16 + fg * 4 + r >= P.Lq) pv[r] = 0.f;
-        }
-        float pk[4] = {pv[0], pv[1], pv[2], pv[3]}, dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
-        if (DROP && P.drop.thresh8) {
-          const unsigned w = mix24(drop_k[nt] + (unsigned)(qb0 + qt * 16) * DROP_CQ);
-          const bool k0_ = (quad_word<0>(w) & drop_bmask) >= drop_bthr, k1_ = (quad_word<1>(w) & drop_bmask) >= drop_bthr;
-          const bool k2_ = (quad_word<2>(w) & drop_bmask) >= drop_bthr, k3_ = (quad_word<3>(w) & drop_bmask) >= drop_bthr;
-          pk[0] = k0_ ? pk[0] : 0.f; dk_[0] = k0_ ? dk_[0] : 0.f;
-          pk[1] = k1_ ? pk[1] : 0.f; dk_[1] = k1_ ? dk_[1] : 0.f;
-          pk[2] = k2_ ? pk[2] : 0.f; dk_[2] = k2_ ? dk_[2] : 0.f;
-          pk[3] = k3_ ? pk[3] : 0.f; dk_[3] = k3_ ? dk_[3] : 0.f;
-        }
+      for (int qt = 0; qt < 2; ++qt) {
+        const bf16x8 qa0 = lds_row8(lq, qt * 16 + fr, fg), qa1 = lds_row8(lq, qt * 16 + fr, 4 + fg);
+        const bf16x8 da0 = lds_row8(ldo_, qt * 16 + fr, fg), da1 = lds_row8(ldo_, qt * 16 + fr, 4 + fg);
+        float lrow[4], drow[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pd[qt][nt][r] = pk[r];
-          ds[qt][nt][r] = pv[r] * fmaf(dk_[r], P.drop.scale, -drow[r]);
+          lrow[r] = lstat[qt * 16 + fg * 4 + r] * LOG2E;
+          drow[r] = ldlt[qt * 16 + fg * 4 + r];
+        }
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int nt = N0 + c;
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (NT == 2) {
+            s = mfma16(qa0, kf[nt][0], s);
+            s = mfma16(qa1, kf[nt][1], s);
+          } else {
+            s = mfma16(qa0, lds_row8(ldsK, key[nt], fg), s);
+            s = mfma16(qa1, lds_row8(ldsK, key[nt], 4 + fg), s);
+          }
+          dp = mfma16(da0, vf[nt][0], dp);
+          dp = mfma16(da1, vf[nt][1], dp);
+          float pv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lrow[r]));
+          if (__builtin_expect(need_mask, 0)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (qb0 + qt * 16 + fg * 4 + r >= P.Lq) pv[r] = 0.f;
+          }
+          if (NT == 3 && key[nt] >= P.Lk) {                  // 256 < Lk < 320: the keys past the end
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = 0.f;
+          }
+          float pk[4] = {pv[0], pv[1], pv[2], pv[3]}, dk_[4] = {dp[0], dp[1], dp[2], dp[3]};
+          if (DROP && P.drop.thresh8) {
+            const unsigned w = mix24(drop_k[nt] + (unsigned)(qb0 + qt * 16) * DROP_CQ);
+            const bool k0_ = (quad_word<0>(w) & drop_bmask) >= drop_bthr, k1_ = (quad_word<1>(w) & drop_bmask) >= drop_bthr;
+            const bool k2_ = (quad_word<2>(w) & drop_bmask) >= drop_bthr, k3_ = (quad_word<3>(w) & drop_bmask) >= drop_bthr;
+            pk[0] = k0_ ? pk[0] : 0.f; dk_[0] = k0_ ? dk_[0] : 0.f;
+            pk[1] = k1_ ? pk[1] : 0.f; dk_[1] = k1_ ? dk_[1] : 0.f;
+            pk[2] = k2_ ? pk[2] : 0.f; dk_[2] = k2_ ? dk_[2] : 0.f;
+            pk[3] = k3_ ? pk[3] : 0.f; dk_[3] = k3_ ? dk_[3] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pd[qt][c][r] = pk[r];
+            ds[qt][c][r] = pv[r] * fmaf(dk_[r], P.drop.scale, -drow[r]);
+          }
         }
       }
-    }
-    unsigned char* X = ldsX + (it & 1) * OP_X_BYTES;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      pdB[nt] = pack8(pd[0][nt], pd[1][nt]);  // k-slot (g,j) <-> q = 16*(j>>2) + 4g + (j&3)
-      dsB[nt] = pack8(ds[0][nt], ds[1][nt]);
-      // dS of key (wave, nt, fr) for the queries 4g..4g+3 of both 16-query tiles: two 8-byte chunks of its row
-      const int row = uw * 32 + nt * 16 + fr, sw = xsw(row);
-      const u32x4 dsw = __builtin_bit_cast(u32x4, dsB[nt]);
-      *(u32x2*)(X + row * 64 + ((fg ^ sw) << 3)) = u32x2{dsw[0], dsw[1]};
-      *(u32x2*)(X + row * 64 + (((4 + fg) ^ sw) << 3)) = u32x2{dsw[2], dsw[3]};
-    }
+      for (int c = 0; c < CNT; ++c) {
+        pdB[c] = pack8(pd[0][c], pd[1][c]);  // k-slot (g,j) <-> q = 16*(j>>2) + 4g + (j&3)
+        dsB[c] = pack8(ds[0][c], ds[1][c]);
+        // dS of key (wave, nt, fr) for the queries 4g..4g+3 of both 16-query tiles: two 8-byte chunks of its row
+        const int row = key[N0 + c], sw = xsw(row);
+        const u32x4 dsw = __builtin_bit_cast(u32x4, dsB[c]);
+        *(u32x2*)(X + row * 64 + ((fg ^ sw) << 3)) = u32x2{dsw[0], dsw[1]};
+        *(u32x2*)(X + row * 64 + (((4 + fg) ^ sw) << 3)) = u32x2{dsw[2], dsw[3]};
+      }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const bf16x8 dot_ = lds_tr8(ldo_, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
-      const bf16x8 qt_ = lds_tr8(lq, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 dot_ = lds_tr8(ldo_, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
+        const bf16x8 qt_ = lds_tr8(lq, fg * 4 + fq, dt * 2 + (fp >> 1), (fp & 1) * 8);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        dvT[nt][dt] = mfma16(dot_, pdB[nt], dvT[nt][dt]);
-        dkT[nt][dt] = mfma16(qt_, dsB[nt], dkT[nt][dt]);
+        for (int c = 0; c < CNT; ++c) {
+          dvT[N0 + c][dt] = mfma16(dot_, pdB[c], dvT[N0 + c][dt]);
+          dkT[N0 + c][dt] = mfma16(qt_, dsB[c], dkT[N0 + c][dt]);
+        }
+      }
+    };
+    phase_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    if constexpr (NT == 3) {
+      if (my_nt == 3) {
+        __builtin_amdgcn_sched_barrier(0);                  // the two passes do not interleave (registers)
+        phase_a(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+      } else {
+        // the idle slot's rows of the exchange buffer are never written by anyone: phase C would read garbage there — waves 4-7
+        // own tiles 5(w-4)+3, +4 only, and the tiles 5w+2 ARE written by waves 0-3: every row of the buffer has exactly one writer
       }
     }
     if (it + 1 < nblk) delta_of(nxt, (it + 1) & 1);
@@ -232,9 +279,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnParams P) 
   dq_of((nblk - 1) & 1, (nblk - 1) * 32);
 
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    bf16_t* dkrow = P.dk + ((size_t)b * OP_LK + key[nt]) * P.lddk + h * HD;
-    bf16_t* dvrow = P.dv + ((size_t)b * OP_LK + key[nt]) * P.lddv + h * HD;
+  for (int nt = 0; nt < NT; ++nt) {
+    if (NT == 3 && (nt >= my_nt || key[nt] >= P.Lk)) continue;
+    bf16_t* dkrow = P.dk + ((size_t)b * P.Lk + key[nt]) * P.lddk + h * HD;
+    bf16_t* dvrow = P.dv + ((size_t)b * P.Lk + key[nt]) * P.lddv + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const f32x4 a = dkT[nt][dt], c = dvT[nt][dt] * P.drop.scale;
@@ -251,9 +299,18 @@ int mrmt3_attn_bwd_onepass_try(const AttnParams& P, hipStream_t s) {
   const bool enabled = MR_KNOB("MRMT3_ATTN_ONEPASS", 1) != 0;     // A/B switch (tuning / tests only)
   const int m = MR_KNOB("MRMT3_ATTN_ONEPASS_MIN_BH", 0);
   if (m > 0) min_bh = m;
-  if (!enabled || P.causal || P.Lk != OP_LK || P.B * P.H < min_bh || P.Lq < 32) return 0;
+  if (!enabled || P.causal || P.B * P.H < min_bh || P.Lq < 32) return 0;
   const dim3 grid((unsigned)P.H, (unsigned)P.B);
-  if (P.drop.thresh8) hipLaunchKernelGGL((attn_bwd_onepass_kernel<true>), grid, dim3(512), 0, s, P);
-  else hipLaunchKernelGGL((attn_bwd_onepass_kernel<false>), grid, dim3(512), 0, s, P);
-  return 1;
+  if (P.Lk == 256) {
+    if (P.drop.thresh8) hipLaunchKernelGGL((attn_bwd_onepass_kernel<true, 2>), grid, dim3(512), 0, s, P);
+    else hipLaunchKernelGGL((attn_bwd_onepass_kernel<false, 2>), grid, dim3(512), 0, s, P);
+    return 1;
+  }
+  // 256 < Lk <= 320 (MR-MT3's own model: 256 encoder frames + 64 memory slots): the 3 + 2 tile form, key tail masked
+  if (P.Lk > 256 && P.Lk <= 320 && MR_KNOB("MRMT3_ATTN_ONEPASS_320", 1) != 0) {
+    if (P.drop.thresh8) hipLaunchKernelGGL((attn_bwd_onepass_kernel<true, 3>), grid, dim3(512), 0, s, P);
+    else hipLaunchKernelGGL((attn_bwd_onepass_kernel<false, 3>), grid, dim3(512), 0, s, P);
+    return 1;
+  }
+  return 0;
 }

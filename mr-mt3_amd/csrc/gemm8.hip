@@ -665,7 +665,11 @@ extern "C" int mrmt3_gemm_nt_geglu(const void* x, int ldx, const void* wi, int l
   MR_CHECK_ARG(rows > 0 && dff > 0 && K > 0 && dff % 8 == 0, "gemm_nt_geglu: bad sizes rows=%d dff=%d K=%d", rows, dff, K);
   MR_CHECK_ARG(ldh >= 2 * dff && ldg >= dff, "gemm_nt_geglu: ldh >= 2 dff and ldg >= dff");
   hipStream_t s = (hipStream_t)stream;
-  bool fused = rows >= 4096 && dff % 128 == 0 && K % 128 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0 &&
+  // (from 2048 rows since round 6 — 4096 before: 12 segments per GPU leave the encoder 3072 rows = 192 tiles of 128 rows, the
+  // same tile count as the unfused product, and the fused launch saves the geglu kernel behind it: 7.60-7.63 -> 7.56-7.59 ms per
+  // 12-segment step, profiles/r06_geglu_fused_min_rows_ab.txt; MRMT3_GEGLU_FUSED_MIN_ROWS moves the line for A/B runs)
+  const int min_rows = MR_KNOB("MRMT3_GEGLU_FUSED_MIN_ROWS", 2048);
+  bool fused = rows >= min_rows && dff % 128 == 0 && K % 128 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0 &&
                ldg % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wi % 16) == 0 && ((uintptr_t)h % 16) == 0 &&
                ((uintptr_t)g % 16) == 0 && ((size_t)rows * ldx + K) * 2 < 0x7FFF0000ull &&
                ((size_t)2 * dff * ldw + K) * 2 < 0x7FFF0000ull;

@@ -470,13 +470,16 @@ def test_attn_bwd_bf16(dev, tile_rows, B, H, Lq, Lk, causal):
     assert _rel(dv, vr.grad) < 2e-2, _rel(dv, vr.grad)
 
 
+@pytest.mark.parametrize("Lk", [256, 320, 300, 272])
 @pytest.mark.parametrize("B,H,Lq,p", [(2, 6, 1024, 0.0), (2, 6, 256, 0.1), (1, 3, 1000, 0.1), (3, 2, 45, 0.0)])
-def test_attn_bwd_onepass_matches_autograd_and_the_two_pass_kernels(dev, knobs, B, H, Lq, p):
-    """The one-pass backward (attention_onepass.hip: 256 keys, not causal — the decoder's cross-attention and the
-    encoder's self-attention) against f32 autograd of the same dropped attention, and against the two-pass kernels on
-    the same inputs (same masks, same bf16 operand roundings: only summation orders differ)."""
+def test_attn_bwd_onepass_matches_autograd_and_the_two_pass_kernels(dev, knobs, B, H, Lq, p, Lk):
+    """The one-pass backward (attention_onepass.hip: not causal, 256 keys — the decoder's cross-attention and the encoder's
+    self-attention — or, round 6, 256 < Lk <= 320 keys in the 3 + 2 tile form: MR-MT3's own cross-attention over 256 frames + 64
+    memory slots, models/t5_segmem_v2_with_prev.py:125-128; 300 and 272 keys exercise the masked key tail, whole idle tiles
+    included) against f32 autograd of the same dropped attention — the mask element by element, from the restatement of the
+    generator — and against the two-pass kernels on the same inputs (same masks, same bf16 operand roundings: only
+    summation orders differ)."""
     from mrmt3 import lib
-    Lk = 256
     g = torch.Generator(device="cpu").manual_seed(Lq * 3 + int(p * 100))
     q = (torch.randn(B * Lq, H * 64, generator=g) * 0.35).to(dev).bfloat16()
     k = torch.randn(B * Lk, H * 64, generator=g).to(dev).bfloat16()
@@ -1198,7 +1201,8 @@ def test_gemm_nt_geglu_fused_equals_the_two_kernels_bitwise(dev, knobs):
     torch.manual_seed(11)
     step = torch.tensor([7], device=dev, dtype=torch.int32)
     for rows, dff, K in ((32768, 1024, 512), (65536 + 200, 1024, 512), (4096, 1024, 512), (8192 + 72, 512, 256),
-                         (1024, 1024, 512), (4096, 320, 512)):
+                         (1024, 1024, 512), (4096, 320, 512),
+                         (3072, 1024, 512), (2048 + 72, 1024, 512)):       # round 6: fused from 2048 rows (12 segments: 3072 encoder rows)
         x = torch.randn(rows, K, device=dev).bfloat16()
         wi = (torch.randn(2 * dff, K, device=dev) * 0.06).bfloat16()
         for p in (0.0, 0.1):
