@@ -101,6 +101,9 @@ def test_bench_shape_loss_logits_and_every_gradient_vs_oracle(variant, tile, kno
     assert counts["gemm_nt8"] >= 40 and counts["gemm_nt_geglu"] >= 16, counts
     assert counts["tn_group"] >= 1 and eng.tn_group.last_info.n_items > 0, counts
     assert counts["attn_fwd"] >= 24 and counts["attn_bwd"] + counts["attn_bwd_onepass"] >= 24, counts
+    # the one-pass attention backward took the encoder's 8 self-attention sites (256 keys) AND the decoder's 8 cross-attention
+    # sites — 256 keys for MT3Net, 320 (256 frames + 64 memory slots) for MR-MT3's own model since round 6
+    assert counts["attn_bwd_onepass"] >= 16, counts
     # ... and the fused backward row kernels (MRMT3_FUSE_ROWS default 6): d_qkv / d_cq -> norm backward (8 encoder + 16
     # decoder sites), d_wo -> gated-GELU backward (16 sites).  A silent fall-back to the two-kernel form fails here.
     assert eng.fuse_rows & 6 == 6, eng.fuse_rows
