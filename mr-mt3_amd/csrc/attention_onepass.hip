@@ -1,6 +1,9 @@
 // K5 backward in ONE pass for the attention shapes whose keys fit one workgroup: 256 keys, not causal — the decoder's
 // cross-attention over the 256 encoder frames (Lq = 1024) and the encoder's self-attention (Lq = 256) of MT3Net, i.e. 16 of
-// the 24 attention sites of a training step (HF T5Attention autograd via models/t5.py:636-648).
+// the 24 attention sites of a training step (HF T5Attention autograd via models/t5.py:636-648) — and, round 6 (NT = 3), 256 < Lk
+// <= 320 keys: the cross-attention of MR-MT3's own model over 256 frames + 64 memory slots (models/t5_segmem_v2_with_prev.py:
+// 125-128), 20 key tiles dealt 3 + 2 over the two waves of a SIMD; profiles/r06_onepass320.txt holds what it took to fit 256
+// registers, its time (190.8 us per site in the step, two-pass 242) and the two re-balancings that lost.
 //
 // The two-pass backward (attention.hip) recomputes S, exp, the dropout mask and dP in both of its kernels: 7 matrix products
 // and two passes of vector work per (query, key) pair, and both kernels are bound by vector-instruction issue.  Here a
